@@ -1,0 +1,189 @@
+/*
+ * ldm_hip.h -- C ABI of the MI355X (gfx950) masked-diffusion training-step library.
+ *
+ * Every entry point takes plain device pointers, sizes and a hipStream_t passed
+ * as void*.  Nothing here allocates, frees or synchronises: outputs and
+ * workspaces are caller-provided (PyTorch owns all memory), work is enqueued on
+ * the given stream and the call returns immediately.
+ *
+ * Return value: 0 on success, a negative LDM_E_* code for a rejected argument,
+ * or a positive hipError_t if a launch failed.  Nothing throws across the ABI.
+ *
+ * Element types: LDM_F32 = float, LDM_BF16 = bfloat16 (raw uint16 storage).
+ * All matrices are row-major; "ld" arguments are row strides in ELEMENTS.
+ *
+ * Each declaration names the reference code it stands in for
+ * (paths relative to the Usefulmaths/Language-Diffusion-Model checkout).
+ */
+#ifndef LDM_HIP_H
+#define LDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LDM_F32 = 0, LDM_BF16 = 1 };
+
+enum {
+  LDM_OK = 0,
+  LDM_E_BADARG = -1,   /* null pointer / negative size */
+  LDM_E_ALIGN = -2,    /* pointer or leading dimension not aligned as required */
+  LDM_E_SHAPE = -3,    /* shape outside what the kernels support */
+  LDM_E_DTYPE = -4,    /* unknown element type */
+  LDM_E_WORKSPACE = -5 /* workspace too small */
+};
+
+int ldm_abi_version(void);
+const char *ldm_error_string(int code);
+
+/* ---------------------------------------------------------------- K1: forward masking
+ * Replaces RandomMaskingStrategy.apply_random_mask (src/masking_strategy.py:88-114)
+ * together with the draw of t in DiffusionLanguageModel.forward (src/model.py:59-68).
+ *   eligible = id not in {bos,eos,pad};  mask = (u < t) & eligible  (fp32 compare)
+ *   masked_out = mask ? mask_id : id;    mask_out = mask (1 byte, 0/1)
+ * u comes from `draw` (fp32 [B*S]) when non-null (parity mode: the caller injects
+ * the reference's torch.rand_like stream), otherwise from Philox4x32-10 keyed by
+ * (seed, offset) inside the kernel (one HBM pass, 17 B/token).
+ * t: t_mode 0 = the scalar t_scalar for every sequence (reference behaviour),
+ *    1 = per-sequence fp32 t_seq[B] (read), 2 = per-sequence t ~ U(eps,1) drawn
+ *    in-kernel from Philox and written to t_seq[B]. */
+int ldm_mask_fwd(const int64_t *ids, const float *draw, int t_mode, float t_scalar,
+                 float *t_seq, float eps, int64_t batch, int64_t seq,
+                 int64_t bos_id, int64_t eos_id, int64_t pad_id, int64_t mask_id,
+                 uint64_t seed, uint64_t offset,
+                 int64_t *masked_out, uint8_t *mask_out, void *stream);
+
+/* ---------------------------------------------------------------- embedding
+ * nn.Embedding forward/backward (src/transformer.py:382,426).
+ * table is fp32 [vocab, d]; out is [T, d] of out_dtype.  Backward scatter-adds
+ * dout rows into the PRE-ZEROED fp32 dtable; rows of `hot_id` (the mask token,
+ * about half of all rows) are summed inside each workgroup first. */
+int ldm_embed_fwd(const int64_t *ids, const float *table, int64_t T, int64_t d, int64_t vocab,
+                  void *out, int out_dtype, void *stream);
+int ldm_embed_bwd(const int64_t *ids, const void *dout, int dtype, int64_t T, int64_t d,
+                  int64_t vocab, int64_t hot_id, float *dtable, void *stream);
+
+/* ---------------------------------------------------------------- RMSNorm
+ * RMSNorm.forward (src/transformer.py:44-60): y = w * x / sqrt(mean(x^2) + eps).
+ * x,y: [T, d] of dtype; w fp32 [d]; rstd fp32 [T] is saved for backward.
+ * Backward: dx = rstd*(dy*w) - x*rstd^3*mean(dy*w*x) (+ dres when non-null, the
+ * residual-stream gradient), dw = sum_t dy*x*rstd.  dw_partial is a workspace of
+ * ldm_rmsnorm_bwd_ws_floats(T,d) floats; dw (fp32 [d]) is overwritten. */
+int ldm_rmsnorm_fwd(const void *x, const float *w, int64_t T, int64_t d, float eps, int dtype,
+                    void *y, float *rstd, void *stream);
+int64_t ldm_rmsnorm_bwd_ws_floats(int64_t T, int64_t d);
+int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd, const void *dy,
+                    const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,
+                    float *dw_partial, void *stream);
+
+/* ---------------------------------------------------------------- RoPE (+ query scale)
+ * RotaryPositionEmbedding.apply_rotary_pos_emb + rotate_half + "q / sqrt(hd)"
+ * (src/transformer.py:98-101,178-185,261).  Works in place on the q and k thirds of
+ * a fused qkv activation [B*S, 3*H*hd] (ld elements per row).  cos/sin are fp32
+ * [S, hd/2] (the reference's tables are cat(freqs,freqs), i.e. the two halves are
+ * equal).  q is multiplied by q_scale after rotation.  inverse != 0 applies the
+ * transpose (backward): the inverse rotation, then the same q_scale. */
+int ldm_rope_qk(void *qkv, int dtype, int64_t batch, int64_t seq, int64_t nhead, int64_t hd,
+                int64_t ld, const float *cos_t, const float *sin_t, float q_scale, int inverse,
+                void *stream);
+
+/* ---------------------------------------------------------------- SwiGLU elementwise
+ * SwiGLU.forward middle line (src/transformer.py:93): h = a * silu(g), where the
+ * fused activation ag is [T, 2F]: a = ag[:, :F] (w1 branch), g = ag[:, F:] (w2 branch).
+ * Backward: da = dh*silu(g); dg = dh*a*sigmoid(g)*(1+g*(1-sigmoid(g))), written to dag. */
+int ldm_swiglu_fwd(const void *ag, int64_t T, int64_t F, int dtype, void *h, void *stream);
+int ldm_swiglu_bwd(const void *ag, const void *dh, int64_t T, int64_t F, int dtype, void *dag,
+                   void *stream);
+
+/* ---------------------------------------------------------------- GEMM (nn.Linear fwd/bwd)
+ * Replaces the nn.Linear calls of src/transformer.py:242-244,288,91-95,441 and their
+ * autograd backward.  C[M,N] = alpha * opA(A)[M,K] * opB(B)[K,N] (+ bias[N]) (+ R[M,N]).
+ *   transA == 0: A stored [M,K] (lda >= K);  transA != 0: A stored [K,M] (lda >= M)
+ *   transB == 0: B stored [K,N] (ldb >= N);  transB != 0: B stored [N,K] (ldb >= K)
+ * in_dtype is the type of A and B; out_dtype the type of C and R; bias is fp32.
+ * Accumulation is fp32.  BF16 inputs run on MFMA and need lda, ldb multiples of 8
+ * and 16-byte aligned A, B; F32 inputs have no alignment requirement.
+ * Batched form: `batch` problems, problem i = (i / batch_inner, i % batch_inner)
+ * offsets its A/B/C by the two element strides given (0 strides broadcast). */
+typedef struct {
+  int64_t outer, inner; /* element strides for the outer and inner batch index */
+} ldm_bstride;
+
+int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+             float alpha, const void *A, int64_t lda, const void *B, int64_t ldb, void *C,
+             int64_t ldc, const float *bias, const void *R, int64_t ldr, void *stream);
+int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N,
+                     int64_t K, float alpha, const void *A, int64_t lda, ldm_bstride sa,
+                     const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,
+                     ldm_bstride sc, int64_t batch, int64_t batch_inner, void *stream);
+
+/* Column sums (bias gradients): out[n] = sum_m X[m,n]; out fp32 [N], overwritten.
+ * ws must hold ldm_colsum_ws_floats(M,N) floats. */
+int64_t ldm_colsum_ws_floats(int64_t M, int64_t N);
+int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
+               void *stream);
+
+/* Elementwise cast fp32 -> bf16 (weight shadows), n elements. */
+int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------- attention
+ * RotaryMultiheadAttention.forward lines 255-285 (src/transformer.py) after the
+ * projections and RoPE: non-causal softmax(q k^T) v per (batch, head) with padded
+ * keys excluded (key_valid: uint8 [B,S], 1 = attend, NULL = all valid; the
+ * reference's masked_fill(-inf) at :271-274).  q is expected pre-scaled.
+ * q, k, v are read from a fused [B*S, 3*H*hd] activation (ld_qkv elements per row;
+ * q at column 0, k at H*hd, v at 2*H*hd); o is [B*S, H*hd] (ld_o).
+ * `saved` keeps what backward needs: BF16: fp32 log-sum-exp [B,H,S];
+ * F32: the probabilities [B,H,S,S].  Size: ldm_attn_saved_bytes().
+ * Backward writes dq,dk,dv into dqkv (same layout as qkv) from do_ and o.
+ * ws: ldm_attn_bwd_ws_bytes() bytes of scratch. */
+int64_t ldm_attn_saved_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd);
+int64_t ldm_attn_bwd_ws_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd);
+int ldm_attn_fwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                 int64_t batch, int64_t nhead, int64_t seq, int64_t hd, void *o, int64_t ld_o,
+                 void *saved, void *stream);
+int ldm_attn_bwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                 int64_t batch, int64_t nhead, int64_t seq, int64_t hd, const void *o,
+                 const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
+                 void *stream);
+
+/* ---------------------------------------------------------------- K4: masked cross-entropy
+ * masked_cross_entropy_loss / variational_lower_bound_loss (src/loss.py:8-65).
+ * A row r of logits [T, V] (ld elements per row) takes part when
+ *   (mask_bool ? mask_bool[r] : masked_ids[r] == mask_token_id) and
+ *   (att_valid == NULL or att_valid[r] != 0).
+ * loss = sum_r w_r * (logsumexp(logits_r) - logits_r[target_r]) / norm, where
+ *   w_r = seq_weight ? seq_weight[r / seq] : 1      (reference: 1)
+ *   norm = norm_mode 0: number of participating rows (reference: mean over masked)
+ *          norm_mode 1: T (the paper's B*L)
+ * and loss = 0 when no row participates.  Only participating rows are read.
+ * Outputs: row_lse fp32 [T] (valid for participating rows), loss_out fp32[1],
+ * count_out fp32[1] (= number of participating rows).  row_tmp: fp32 [T] scratch.
+ * Backward writes dlogits[T, V] (dtype, ld_d per row; zero for other rows and for
+ * padding columns V..ld_d-1): (softmax - onehot) * w_r * gout[0] / norm. */
+int ldm_ce_fwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, int64_t seq,
+               const int64_t *targets, const int64_t *masked_ids, int64_t mask_token_id,
+               const uint8_t *mask_bool, const uint8_t *att_valid, const float *seq_weight,
+               int norm_mode, float *row_lse, float *row_tmp, float *loss_out, float *count_out,
+               void *stream);
+int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, int64_t seq,
+               const int64_t *targets, const int64_t *masked_ids, int64_t mask_token_id,
+               const uint8_t *mask_bool, const uint8_t *att_valid, const float *seq_weight,
+               int norm_mode, const float *row_lse, const float *count, const float *gout,
+               void *dlogits, int64_t ld_d, void *stream);
+
+/* ---------------------------------------------------------------- fp32 softmax helpers
+ * Used by the F32 attention path (materialised scores, as the reference does at
+ * src/transformer.py:264-281).  Exposed for testing. */
+int ldm_softmax_rows_f32(float *scores, const uint8_t *key_valid, int64_t batch, int64_t nhead,
+                         int64_t seq_q, int64_t seq_k, void *stream);
+int ldm_softmax_bwd_rows_f32(const float *probs, float *dprobs_inout, int64_t rows, int64_t cols,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM_HIP_H */

@@ -1,0 +1,14 @@
+// Internal attention entry points (C-ABI wrappers live in attn_api.hip).
+#pragma once
+#include "common.h"
+
+int ldm_attn_fwd_f32(const float *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
+                     int64_t hd, float *o, int64_t ld_o, float *probs, hipStream_t s);
+int ldm_attn_bwd_f32(const float *qkv, int64_t ld, int64_t B, int64_t H, int64_t S, int64_t hd, const float *dout,
+                     int64_t ld_o, const float *probs, float *dqkv, float *dprobs, hipStream_t s);
+
+int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
+                       int64_t hd, bf16_t *o, int64_t ld_o, float *lse, hipStream_t s);
+int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
+                       int64_t hd, const bf16_t *o, const bf16_t *dout, int64_t ld_o, const float *lse,
+                       bf16_t *dqkv, float *delta, hipStream_t s);

@@ -1,0 +1,47 @@
+// C-ABI attention dispatch: BF16 -> flash kernels, F32 -> materialised-score path.
+#include "common.h"
+#include "attn.h"
+
+extern "C" int64_t ldm_attn_saved_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd) {
+  (void)hd;
+  if (dtype == LDM_BF16) return batch * nhead * seq * (int64_t)sizeof(float);
+  return batch * nhead * seq * seq * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t ldm_attn_bwd_ws_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd) {
+  return ldm_attn_saved_bytes(dtype, batch, nhead, seq, hd);
+}
+
+extern "C" int ldm_attn_fwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,
+                            int64_t nhead, int64_t seq, int64_t hd, void *o, int64_t ld_o, void *saved,
+                            void *stream) {
+  if (batch < 0 || nhead <= 0 || seq < 0 || hd <= 0) return LDM_E_BADARG;
+  if (batch == 0 || seq == 0) return LDM_OK;
+  if (!qkv || !o || !saved) return LDM_E_BADARG;
+  if (ld_qkv < 3 * nhead * hd || ld_o < nhead * hd) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_BF16)
+    return ldm_flash_fwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (bf16_t *)o, ld_o,
+                              (float *)saved, s);
+  if (dtype == LDM_F32)
+    return ldm_attn_fwd_f32((const float *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (float *)o, ld_o,
+                            (float *)saved, s);
+  return LDM_E_DTYPE;
+}
+
+extern "C" int ldm_attn_bwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,
+                            int64_t nhead, int64_t seq, int64_t hd, const void *o, const void *do_, int64_t ld_o,
+                            const void *saved, void *dqkv, void *ws, void *stream) {
+  if (batch < 0 || nhead <= 0 || seq < 0 || hd <= 0) return LDM_E_BADARG;
+  if (batch == 0 || seq == 0) return LDM_OK;
+  if (!qkv || !o || !do_ || !saved || !dqkv || !ws) return LDM_E_BADARG;
+  if (ld_qkv < 3 * nhead * hd || ld_o < nhead * hd) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_BF16)
+    return ldm_flash_bwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (const bf16_t *)o,
+                              (const bf16_t *)do_, ld_o, (const float *)saved, (bf16_t *)dqkv, (float *)ws, s);
+  if (dtype == LDM_F32)
+    return ldm_attn_bwd_f32((const float *)qkv, ld_qkv, batch, nhead, seq, hd, (const float *)do_, ld_o,
+                            (const float *)saved, (float *)dqkv, (float *)ws, s);
+  return LDM_E_DTYPE;
+}

@@ -1,0 +1,525 @@
+// Non-causal flash attention, forward and backward, bf16 on v_mfma_f32_32x32x16_bf16.
+// Replaces src/transformer.py:255-285 (scores, key-padding mask, softmax, PV) and its
+// autograd backward without materialising the S x S scores.
+//
+// Layout: q, k, v live in one fused activation [B*S, 3*H*hd]; a workgroup is 4 waves
+// and owns 128 rows (queries, or keys in the dK/dV kernel) of one (batch, head), 32 per
+// wave; the other side streams through LDS in 64-row tiles (global -> registers ->
+// LDS, loads issued one tile ahead).
+//
+// Orientation: scores are computed TRANSPOSED, S^T = K Q^T (keys on the accumulator
+// rows, the query on the lane), so the softmax statistics of a query are per-lane
+// scalars and the fp32 accumulator, packed to bf16, is directly the B operand of the
+// next product (O^T = V^T P^T, dQ^T = K^T dS^T).  The dK/dV kernel uses the other
+// orientation (S = Q K^T, key on the lane) for the same reason.  The matching A
+// operand needs its k index in the accumulator's row order
+// (16s + 8(j>>2) + 4*half + (j&3)); ds_read_b64_tr_b16 delivers exactly that from a
+// row-major [row][d] LDS tile.
+#include "common.h"
+#include "attn.h"
+
+namespace {
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DP>
+struct AT {
+  static constexpr int NK = DP / 16;          // 16-deep k steps over the head dim
+  static constexpr int ND = DP / 32;          // 32-wide blocks of the head dim
+  static constexpr int RSTR = DP * 2 + 16;    // row stride (bytes) of tiles read by rows: odd multiple of 16 B
+  static constexpr int TSTR = ((DP * 2) % 128 == 64) ? DP * 2 : DP * 2 + 64;   // tiles read transposed only
+  static constexpr int NCH = DP * 8 / 256;    // 16-B chunks per thread for a 64-row tile
+  static constexpr int CPR = DP / 8;          // 16-B chunks per tile row
+};
+
+struct FArgs {
+  const bf16_t *qkv; int64_t ld;
+  const uint8_t *key_valid;
+  int B, H, S, hd;
+  bf16_t *o; const bf16_t *o_in; const bf16_t *dout; int64_t ld_o;
+  float *lse; const float *lse_in;
+  bf16_t *dqkv; float *delta;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// 64 rows x DP columns, rows >= S and columns >= hd zero-filled
+template <int DP>
+__device__ __forceinline__ void tile_load(const bf16_t *base, int64_t ld, int row0, int S, int hd, int tid,
+                                          uint4 (&r)[AT<DP>::NCH]) {
+#pragma unroll
+  for (int i = 0; i < AT<DP>::NCH; ++i) {
+    const int c = tid + i * 256;
+    const int row = c / AT<DP>::CPR, c8 = c - row * AT<DP>::CPR;
+    const int grow = row0 + row;
+    if (grow < S && c8 * 8 < hd)
+      r[i] = *reinterpret_cast<const uint4 *>(base + (int64_t)grow * ld + c8 * 8);
+    else
+      r[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <int DP, int STR>
+__device__ __forceinline__ void tile_store(char *tile, int tid, const uint4 (&r)[AT<DP>::NCH]) {
+#pragma unroll
+  for (int i = 0; i < AT<DP>::NCH; ++i) {
+    const int c = tid + i * 256;
+    const int row = c / AT<DP>::CPR, c8 = c - row * AT<DP>::CPR;
+    *reinterpret_cast<uint4 *>(tile + row * STR + c8 * 16) = r[i];
+  }
+}
+
+// MFMA operand with the tile ROW on the operand's row/col index and k = head dim
+template <int STR>
+__device__ __forceinline__ bf8_t row_frag(const char *tile, int row, int kk, int half) {
+  return *reinterpret_cast<const bf8_t *>(tile + row * STR + kk * 32 + half * 16);
+}
+// MFMA A operand with the head dim (block dblk) on the operand's row and k = tile rows
+// rbase .. rbase+15 in accumulator-row order
+template <int STR>
+__device__ __forceinline__ bf8_t tr_frag(const char *tile, int rbase, int dblk, int lane) {
+  const int half = lane >> 5, gg = (lane >> 4) & 1, i = lane & 15;
+  const char *a0 = tile + (rbase + 4 * half + (i >> 2)) * STR + (dblk * 32 + 16 * gg + 4 * (i & 3)) * 2;
+  s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0));
+  s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0 + 8 * STR));
+  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8_t, v);
+}
+// direct-from-global operand: row `row` of a [rows][hd] matrix, k = 16*kk + 8*half + 0..7
+__device__ __forceinline__ bf8_t global_frag(const bf16_t *base, int64_t ld, int row, bool row_ok, int kk,
+                                             int half, int hd) {
+  const int d = 16 * kk + 8 * half;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (row_ok && d < hd) v = *reinterpret_cast<const uint4 *>(base + (int64_t)row * ld + d);
+  return __builtin_bit_cast(bf8_t, v);
+}
+__device__ __forceinline__ bf8_t pack8(const float *p) {
+  bf8_t r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)p[j];
+  return r;
+}
+// accumulator register r of a 32x32 tile sits on row (r&3) + 8*(r>>2) + 4*half
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// store an accumulator tile transposed: lane owns matrix row `row`, registers run over d
+template <int DP>
+__device__ __forceinline__ void store_rows(bf16_t *dst_row, const f16_t (&acc)[AT<DP>::ND], float scale,
+                                           int half, int hd) {
+#pragma unroll
+  for (int db = 0; db < AT<DP>::ND; ++db)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int d = db * 32 + 8 * r4 + 4 * half;
+      if (d < hd) {
+        f4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v.v[j] = acc[db][4 * r4 + j] * scale;
+        st4(dst_row + d, v);
+      }
+    }
+}
+
+// --------------------------------------------------------------------------- forward
+template <int DP>
+__global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
+  using T = AT<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *Kt = smem;
+  char *Vt = smem + 64 * T::RSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, c = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, hd = a.hd;
+  const int64_t D = (int64_t)a.H * hd;
+  const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
+  const bf16_t *kb = qb + D, *vb = qb + 2 * D;
+  const int q = blockIdx.x * 128 + wave * 32 + c;
+
+  bf8_t qf[T::NK];
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk) qf[kk] = global_frag(qb, a.ld, q < S ? q : S - 1, true, kk, half, hd);
+
+  f16_t oacc[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  const int nt = (S + 63) / 64;
+  uint4 kr[T::NCH], vr[T::NCH];
+  tile_load<DP>(kb, a.ld, 0, S, hd, tid, kr);
+  tile_load<DP>(vb, a.ld, 0, S, hd, tid, vr);
+  tile_store<DP, T::RSTR>(Kt, tid, kr);
+  tile_store<DP, T::TSTR>(Vt, tid, vr);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * 64;
+    if (t + 1 < nt) {
+      tile_load<DP>(kb, a.ld, k0 + 64, S, hd, tid, kr);
+      tile_load<DP>(vb, a.ld, k0 + 64, S, hd, tid, vr);
+    }
+    bool kok = (k0 + lane) < S;
+    if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
+    const unsigned long long valid = __ballot(kok);
+
+    f16_t sacc[2];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < T::NK; ++kk)
+        sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<T::RSTR>(Kt, kbk * 32 + c, kk, half), qf[kk],
+                                                            sacc[kbk], 0, 0, 0);
+    }
+    if (valid != ~0ull) {
+      const unsigned long long vs = valid >> (4 * half);
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!((vs >> (kbk * 32 + acc_row(r))) & 1ull)) sacc[kbk][r] = -INFINITY;
+    }
+    float mx = m;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kbk][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mu = (mx == -INFINITY) ? 0.f : mx;
+    const float alpha = fast_exp2((m - mu) * LOG2E);
+    m = mx;
+    float ps = 0.f;
+    const float mneg = -mu * LOG2E;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(sacc[kbk][r], LOG2E, mneg));
+        sacc[kbk][r] = p;
+        ps += p;
+      }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = sacc[kbk][8 * s + j];
+        const bf8_t pf = pack8(tmp);
+#pragma unroll
+        for (int db = 0; db < T::ND; ++db)
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<T::TSTR>(Vt, kbk * 32 + 16 * s, db, lane), pf,
+                                                             oacc[db], 0, 0, 0);
+      }
+    __syncthreads();
+    if (t + 1 < nt) {
+      tile_store<DP, T::RSTR>(Kt, tid, kr);
+      tile_store<DP, T::TSTR>(Vt, tid, vr);
+      __syncthreads();
+    }
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (q < S) {
+    store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
+    if (half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
+  }
+}
+
+// --------------------------------------------------------------------------- delta
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+__global__ __launch_bounds__(256) void attn_delta_k(FArgs a) {
+  const int64_t total = (int64_t)a.B * a.S * a.H;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / a.H;
+    const int head = (int)(idx - row * a.H);
+    const bf16_t *o = a.o_in + row * a.ld_o + (int64_t)head * a.hd;
+    const bf16_t *g = a.dout + row * a.ld_o + (int64_t)head * a.hd;
+    float s = 0.f;
+    for (int d = 0; d < a.hd; d += 4) {
+      const f4 x = ld4(o + d), y = ld4(g + d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(x.v[j], y.v[j], s);
+    }
+    const int64_t bb = row / a.S, qq = row - bb * a.S;
+    a.delta[(bb * a.H + head) * a.S + qq] = s;
+  }
+}
+
+// --------------------------------------------------------------------------- dQ
+template <int DP>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
+  using T = AT<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *Kt = smem;
+  char *Vt = smem + 64 * T::RSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, c = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, hd = a.hd;
+  const int64_t D = (int64_t)a.H * hd;
+  const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
+  const bf16_t *kb = qb + D, *vb = qb + 2 * D;
+  const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
+  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int qc = q < S ? q : S - 1;
+
+  bf8_t qf[T::NK], dof[T::NK];
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk) {
+    qf[kk] = global_frag(qb, a.ld, qc, true, kk, half, hd);
+    dof[kk] = global_frag(dob, a.ld_o, qc, true, kk, half, hd);
+  }
+  const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
+  const float nlse = -a.lse_in[stat] * LOG2E;
+  const float dlt = a.delta[stat];
+
+  f16_t dq[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  const int nt = (S + 63) / 64;
+  uint4 kr[T::NCH], vr[T::NCH];
+  tile_load<DP>(kb, a.ld, 0, S, hd, tid, kr);
+  tile_load<DP>(vb, a.ld, 0, S, hd, tid, vr);
+  tile_store<DP, T::RSTR>(Kt, tid, kr);
+  tile_store<DP, T::RSTR>(Vt, tid, vr);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * 64;
+    if (t + 1 < nt) {
+      tile_load<DP>(kb, a.ld, k0 + 64, S, hd, tid, kr);
+      tile_load<DP>(vb, a.ld, k0 + 64, S, hd, tid, vr);
+    }
+    bool kok = (k0 + lane) < S;
+    if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
+    const unsigned long long vs = __ballot(kok) >> (4 * half);
+
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+      f16_t sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < T::NK; ++kk) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<T::RSTR>(Kt, kbk * 32 + c, kk, half), qf[kk], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<T::RSTR>(Vt, kbk * 32 + c, kk, half), dof[kk], dpacc, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = (vs >> (kbk * 32 + acc_row(r))) & 1ull;
+        const float p = ok ? fast_exp2(fmaf(sacc[r], LOG2E, nlse)) : 0.f;
+        ds[r] = p * (dpacc[r] - dlt);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf8_t dsf = pack8(ds + 8 * s);
+#pragma unroll
+        for (int db = 0; db < T::ND; ++db)
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<T::RSTR>(Kt, kbk * 32 + 16 * s, db, lane), dsf,
+                                                           dq[db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (t + 1 < nt) {
+      tile_store<DP, T::RSTR>(Kt, tid, kr);
+      tile_store<DP, T::RSTR>(Vt, tid, vr);
+      __syncthreads();
+    }
+  }
+  if (q < S) store_rows<DP>(a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd, dq, 1.0f, half, hd);
+}
+
+// --------------------------------------------------------------------------- dK, dV
+template <int DP>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
+  using T = AT<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *Qt = smem;
+  char *Gt = smem + 64 * T::RSTR;                                   // dO tile
+  float *lse_s = reinterpret_cast<float *>(smem + 128 * T::RSTR);   // [64] -lse*log2e (or -inf)
+  float *dlt_s = lse_s + 64;                                         // [64] -delta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, c = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, hd = a.hd;
+  const int64_t D = (int64_t)a.H * hd;
+  const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
+  const bf16_t *kb = qb + D, *vb = qb + 2 * D;
+  const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
+  const int key = blockIdx.x * 128 + wave * 32 + c;
+  bool key_ok = key < S;
+  if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
+  const int keyc = key < S ? key : S - 1;
+
+  bf8_t kf[T::NK], vf[T::NK];
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk) {
+    kf[kk] = global_frag(kb, a.ld, keyc, key < S, kk, half, hd);
+    vf[kk] = global_frag(vb, a.ld, keyc, key < S, kk, half, hd);
+  }
+  f16_t dk[T::ND], dv[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  const int64_t stat0 = ((int64_t)b * a.H + head) * S;
+  const int nt = (S + 63) / 64;
+  uint4 qr[T::NCH], gr[T::NCH];
+  float lse_r = 0.f, dlt_r = 0.f;
+  auto load_stats = [&](int q0) {
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      lse_r = qq < S ? -a.lse_in[stat0 + qq] * LOG2E : -INFINITY;
+      dlt_r = qq < S ? -a.delta[stat0 + qq] : 0.f;
+    }
+  };
+  auto store_stats = [&]() {
+    if (tid < 64) { lse_s[tid] = lse_r; dlt_s[tid] = dlt_r; }
+  };
+  tile_load<DP>(qb, a.ld, 0, S, hd, tid, qr);
+  tile_load<DP>(dob, a.ld_o, 0, S, hd, tid, gr);
+  load_stats(0);
+  tile_store<DP, T::RSTR>(Qt, tid, qr);
+  tile_store<DP, T::RSTR>(Gt, tid, gr);
+  store_stats();
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+      tile_load<DP>(qb, a.ld, (t + 1) * 64, S, hd, tid, qr);
+      tile_load<DP>(dob, a.ld_o, (t + 1) * 64, S, hd, tid, gr);
+      load_stats((t + 1) * 64);
+    }
+#pragma unroll
+    for (int qbk = 0; qbk < 2; ++qbk) {
+      f16_t sacc, dpacc;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 l4 = *reinterpret_cast<const float4 *>(lse_s + qbk * 32 + 8 * r4 + 4 * half);
+        const float4 d4 = *reinterpret_cast<const float4 *>(dlt_s + qbk * 32 + 8 * r4 + 4 * half);
+        sacc[4 * r4 + 0] = l4.x; sacc[4 * r4 + 1] = l4.y; sacc[4 * r4 + 2] = l4.z; sacc[4 * r4 + 3] = l4.w;
+        dpacc[4 * r4 + 0] = d4.x; dpacc[4 * r4 + 1] = d4.y; dpacc[4 * r4 + 2] = d4.z; dpacc[4 * r4 + 3] = d4.w;
+      }
+      // sacc holds the row constants -lse*log2e; dpacc starts at -delta so that the
+      // MFMA chain leaves dP - delta.
+      f16_t s0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < T::NK; ++kk) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<T::RSTR>(Qt, qbk * 32 + c, kk, half), kf[kk], s0, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<T::RSTR>(Gt, qbk * 32 + c, kk, half), vf[kk], dpacc, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = key_ok ? fast_exp2(fmaf(s0[r], LOG2E, sacc[r])) : 0.f;
+        p[r] = pr;
+        ds[r] = pr * dpacc[r];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf8_t pf = pack8(p + 8 * s), dsf = pack8(ds + 8 * s);
+#pragma unroll
+        for (int db = 0; db < T::ND; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<T::RSTR>(Gt, qbk * 32 + 16 * s, db, lane), pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<T::RSTR>(Qt, qbk * 32 + 16 * s, db, lane), dsf, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < nt) {
+      tile_store<DP, T::RSTR>(Qt, tid, qr);
+      tile_store<DP, T::RSTR>(Gt, tid, gr);
+      store_stats();
+      __syncthreads();
+    }
+  }
+  if (key < S) {
+    bf16_t *row = a.dqkv + ((int64_t)b * S + key) * a.ld + (int64_t)head * hd;
+    store_rows<DP>(row + D, dk, 1.0f, half, hd);
+    store_rows<DP>(row + 2 * D, dv, 1.0f, half, hd);
+  }
+}
+
+template <int DP>
+int flash_fwd_launch(const FArgs &a, hipStream_t s) {
+  const size_t lds = 64 * AT<DP>::RSTR + 64 * AT<DP>::TSTR;
+  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  hipLaunchKernelGGL(flash_fwd_k<DP>, grid, dim3(256), lds, s, a);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <int DP>
+int flash_bwd_launch(const FArgs &a, hipStream_t s) {
+  int64_t nb = ceil_div((int64_t)a.B * a.S * a.H, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)nb), dim3(256), 0, s, a);
+  LDM_CHECK_LAUNCH();
+  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  hipLaunchKernelGGL(flash_bwd_dq_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
+  LDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(flash_bwd_dkv_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR + 512, s, a);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+int check(const FArgs &a) {
+  if (a.B <= 0 || a.H <= 0 || a.S <= 0 || a.hd <= 0) return LDM_E_BADARG;
+  if (a.hd % 8 || a.hd > 128) return LDM_E_SHAPE;
+  if (a.ld % 8 || a.ld_o % 8) return LDM_E_ALIGN;
+  if (a.B > 65535 || a.H > 65535) return LDM_E_SHAPE;
+  return LDM_OK;
+}
+
+}  // namespace
+
+int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
+                       int64_t hd, bf16_t *o, int64_t ld_o, float *lse, hipStream_t s) {
+  FArgs a{};
+  a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
+  a.o = o; a.ld_o = ld_o; a.lse = lse;
+  int rc = check(a);
+  if (rc) return rc;
+  if (!aligned_to(qkv, 16) || !aligned_to(o, 8)) return LDM_E_ALIGN;
+  if (hd <= 32) return flash_fwd_launch<32>(a, s);
+  if (hd <= 64) return flash_fwd_launch<64>(a, s);
+  if (hd <= 96) return flash_fwd_launch<96>(a, s);
+  return flash_fwd_launch<128>(a, s);
+}
+
+int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
+                       int64_t hd, const bf16_t *o, const bf16_t *dout, int64_t ld_o, const float *lse,
+                       bf16_t *dqkv, float *delta, hipStream_t s) {
+  FArgs a{};
+  a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
+  a.o_in = o; a.dout = dout; a.ld_o = ld_o; a.lse_in = lse; a.dqkv = dqkv; a.delta = delta;
+  int rc = check(a);
+  if (rc) return rc;
+  if (!aligned_to(qkv, 16) || !aligned_to(dout, 16) || !aligned_to(o, 8) || !aligned_to(dqkv, 8)) return LDM_E_ALIGN;
+  if (hd <= 32) return flash_bwd_launch<32>(a, s);
+  if (hd <= 64) return flash_bwd_launch<64>(a, s);
+  if (hd <= 96) return flash_bwd_launch<96>(a, s);
+  return flash_bwd_launch<128>(a, s);
+}

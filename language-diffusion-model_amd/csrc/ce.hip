@@ -1,0 +1,259 @@
+// K4: masked cross-entropy with a streamed log-sum-exp (HBM-bound: one read of the
+// participating logit rows forward, one read + one write backward).
+// Follows masked_cross_entropy_loss / variational_lower_bound_loss (src/loss.py:8-65).
+#include "common.h"
+
+namespace {
+
+struct CeArgs {
+  int64_t ld, T, V, seq;
+  const int64_t *targets;
+  const int64_t *masked_ids;
+  int64_t mask_token_id;
+  const uint8_t *mask_bool;
+  const uint8_t *att_valid;
+  const float *seq_weight;
+  int norm_mode;
+};
+
+__device__ __forceinline__ bool row_active(const CeArgs &a, int64_t r) {
+  bool m = a.mask_bool ? (a.mask_bool[r] != 0) : (a.masked_ids[r] == a.mask_token_id);
+  if (a.att_valid) m = m && (a.att_valid[r] != 0);
+  return m;
+}
+
+// (max, sum of exp relative to max) pair and its merge
+struct MS { float m, s; };
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+  const float m = fmaxf(a.m, b.m);
+  if (m == -INFINITY) return MS{m, 0.f};
+  return MS{m, a.s * __expf(a.m - m) + b.s * __expf(b.m - m)};
+}
+__device__ __forceinline__ void ms_push(MS &a, float x) {
+  if (x > a.m) {
+    a.s = a.s * __expf(a.m - x) + 1.0f;
+    a.m = x;
+  } else {
+    a.s += __expf(x - a.m);
+  }
+}
+
+// One 256-thread block per row; inactive rows leave after one flag read.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void ce_fwd_rows_k(const T *logits, CeArgs a, float *row_lse,
+                                                     float *row_loss) {
+  const int64_t r = blockIdx.x;
+  if (!row_active(a, r)) {
+    if (threadIdx.x == 0) row_loss[r] = 0.f;
+    return;
+  }
+  const T *row = logits + r * a.ld;
+  MS acc{-INFINITY, 0.f};
+  if (VEC) {
+    const int64_t nv = a.V >> 2;
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+      f4 v = ld4(row + i * 4);
+      const float mx = fmaxf(fmaxf(v.v[0], v.v[1]), fmaxf(v.v[2], v.v[3]));
+      if (mx > acc.m) {
+        acc.s *= __expf(acc.m - mx);
+        acc.m = mx;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc.s += __expf(v.v[j] - acc.m);
+    }
+    for (int64_t i = (nv << 2) + threadIdx.x; i < a.V; i += 256) ms_push(acc, Elt<T>::ld(row + i));
+  } else {
+    for (int64_t i = threadIdx.x; i < a.V; i += 256) ms_push(acc, Elt<T>::ld(row + i));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MS other{__shfl_xor(acc.m, o, 64), __shfl_xor(acc.s, o, 64)};
+    acc = ms_merge(acc, other);
+  }
+  __shared__ float sm_m[4], sm_s[4];
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm_m[wid] = acc.m;
+    sm_s[wid] = acc.s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    MS t{sm_m[0], sm_s[0]};
+    for (int w = 1; w < 4; ++w) t = ms_merge(t, MS{sm_m[w], sm_s[w]});
+    const float lse = t.m + logf(t.s);
+    const int64_t tgt = a.targets[r];
+    const float xt = (tgt >= 0 && tgt < a.V) ? Elt<T>::ld(row + tgt) : 0.f;
+    const float w = a.seq_weight ? a.seq_weight[r / a.seq] : 1.0f;
+    row_lse[r] = lse;
+    row_loss[r] = w * (lse - xt);
+  }
+}
+
+// Single block: deterministic sum of the per-row losses and the active-row count.
+__global__ __launch_bounds__(1024) void ce_finish_k(const float *row_loss, CeArgs a, float *loss_out,
+                                                    float *count_out) {
+  __shared__ double sm_l[16];
+  __shared__ float sm_c[16];
+  double l = 0.0;
+  float c = 0.f;
+  for (int64_t r = threadIdx.x; r < a.T; r += 1024) {
+    if (row_active(a, r)) {
+      l += (double)row_loss[r];
+      c += 1.0f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    l += __shfl_xor(l, o, 64);
+    c += __shfl_xor(c, o, 64);
+  }
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm_l[wid] = l;
+    sm_c[wid] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tl = 0.0;
+    float tc = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      tl += sm_l[w];
+      tc += sm_c[w];
+    }
+    const float norm = a.norm_mode == 0 ? tc : (float)a.T;
+    loss_out[0] = (tc > 0.f && norm > 0.f) ? (float)(tl / (double)norm) : 0.f;
+    count_out[0] = tc;
+  }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void ce_bwd_rows_k(const T *logits, CeArgs a, const float *row_lse,
+                                                     const float *count, const float *gout, T *dl,
+                                                     int64_t ld_d) {
+  const int64_t r = blockIdx.x;
+  T *drow = dl + r * ld_d;
+  const bool act = row_active(a, r);
+  if (!act) {
+    if (VEC) {
+      const f4 z{{0.f, 0.f, 0.f, 0.f}};
+      for (int64_t i = threadIdx.x; i < (ld_d >> 2); i += 256) st4(drow + i * 4, z);
+    } else {
+      for (int64_t i = threadIdx.x; i < ld_d; i += 256) Elt<T>::st(drow + i, 0.f);
+    }
+    return;
+  }
+  const T *row = logits + r * a.ld;
+  const float cnt = count[0];
+  const float norm = a.norm_mode == 0 ? cnt : (float)a.T;
+  const float w = a.seq_weight ? a.seq_weight[r / a.seq] : 1.0f;
+  const float coef = gout[0] * w / norm;
+  const float lse = row_lse[r];
+  const int64_t tgt = a.targets[r];
+  if (VEC) {
+    const int64_t nv = a.V >> 2;
+    for (int64_t i = threadIdx.x; i < (ld_d >> 2); i += 256) {
+      f4 o{{0.f, 0.f, 0.f, 0.f}};
+      if (i < nv) {
+        f4 v = ld4(row + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = __expf(v.v[j] - lse);
+          o.v[j] = (p - ((i * 4 + j) == tgt ? 1.0f : 0.f)) * coef;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t c = i * 4 + j;
+          if (c < a.V) {
+            const float p = __expf(Elt<T>::ld(row + c) - lse);
+            o.v[j] = (p - (c == tgt ? 1.0f : 0.f)) * coef;
+          }
+        }
+      }
+      st4(drow + i * 4, o);
+    }
+  } else {
+    for (int64_t c = threadIdx.x; c < ld_d; c += 256) {
+      float o = 0.f;
+      if (c < a.V) {
+        const float p = __expf(Elt<T>::ld(row + c) - lse);
+        o = (p - (c == tgt ? 1.0f : 0.f)) * coef;
+      }
+      Elt<T>::st(drow + c, o);
+    }
+  }
+}
+
+}  // namespace
+
+static int ce_args(CeArgs &a, int64_t ld, int64_t T, int64_t V, int64_t seq, const int64_t *targets,
+                   const int64_t *masked_ids, int64_t mask_token_id, const uint8_t *mask_bool,
+                   const uint8_t *att_valid, const float *seq_weight, int norm_mode) {
+  if (T < 0 || V <= 0 || ld < V) return LDM_E_BADARG;
+  if (!targets || (!masked_ids && !mask_bool)) return LDM_E_BADARG;
+  if (norm_mode != 0 && norm_mode != 1) return LDM_E_BADARG;
+  if (seq <= 0) seq = 1;
+  a.ld = ld; a.T = T; a.V = V; a.seq = seq; a.targets = targets; a.masked_ids = masked_ids;
+  a.mask_token_id = mask_token_id; a.mask_bool = mask_bool; a.att_valid = att_valid;
+  a.seq_weight = seq_weight; a.norm_mode = norm_mode;
+  return LDM_OK;
+}
+
+extern "C" int ldm_ce_fwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, int64_t seq,
+                          const int64_t *targets, const int64_t *masked_ids, int64_t mask_token_id,
+                          const uint8_t *mask_bool, const uint8_t *att_valid, const float *seq_weight,
+                          int norm_mode, float *row_lse, float *row_tmp, float *loss_out,
+                          float *count_out, void *stream) {
+  CeArgs a;
+  int rc = ce_args(a, ld, T, V, seq, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode);
+  if (rc) return rc;
+  if (!loss_out || !count_out) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (T > 0) {
+    if (!logits || !row_lse || !row_tmp) return LDM_E_BADARG;
+    if (T > 0x7fffffff) return LDM_E_SHAPE;
+    const size_t esz = dtype == LDM_F32 ? 4 : 2;
+    const bool vec = aligned_to(logits, 4 * esz) && ((ld * esz) % (4 * esz) == 0);
+    if (dtype == LDM_F32) {
+      if (vec) hipLaunchKernelGGL((ce_fwd_rows_k<float, true>), dim3((unsigned)T), dim3(256), 0, s, (const float *)logits, a, row_lse, row_tmp);
+      else hipLaunchKernelGGL((ce_fwd_rows_k<float, false>), dim3((unsigned)T), dim3(256), 0, s, (const float *)logits, a, row_lse, row_tmp);
+    } else if (dtype == LDM_BF16) {
+      if (vec) hipLaunchKernelGGL((ce_fwd_rows_k<bf16_t, true>), dim3((unsigned)T), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, row_tmp);
+      else hipLaunchKernelGGL((ce_fwd_rows_k<bf16_t, false>), dim3((unsigned)T), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, row_tmp);
+    } else {
+      return LDM_E_DTYPE;
+    }
+    LDM_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(ce_finish_k, dim3(1), dim3(1024), 0, s, row_tmp, a, loss_out, count_out);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, int64_t seq,
+                          const int64_t *targets, const int64_t *masked_ids, int64_t mask_token_id,
+                          const uint8_t *mask_bool, const uint8_t *att_valid, const float *seq_weight,
+                          int norm_mode, const float *row_lse, const float *count, const float *gout,
+                          void *dlogits, int64_t ld_d, void *stream) {
+  CeArgs a;
+  int rc = ce_args(a, ld, T, V, seq, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode);
+  if (rc) return rc;
+  if (T == 0) return LDM_OK;
+  if (!logits || !row_lse || !count || !gout || !dlogits || ld_d < V) return LDM_E_BADARG;
+  if (T > 0x7fffffff) return LDM_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype == LDM_F32 ? 4 : 2;
+  const bool vec = aligned_to(logits, 4 * esz) && ((ld * esz) % (4 * esz) == 0) &&
+                   aligned_to(dlogits, 4 * esz) && ((ld_d * esz) % (4 * esz) == 0);
+  if (dtype == LDM_F32) {
+    if (vec) hipLaunchKernelGGL((ce_bwd_rows_k<float, true>), dim3((unsigned)T), dim3(256), 0, s, (const float *)logits, a, row_lse, count, gout, (float *)dlogits, ld_d);
+    else hipLaunchKernelGGL((ce_bwd_rows_k<float, false>), dim3((unsigned)T), dim3(256), 0, s, (const float *)logits, a, row_lse, count, gout, (float *)dlogits, ld_d);
+  } else if (dtype == LDM_BF16) {
+    if (vec) hipLaunchKernelGGL((ce_bwd_rows_k<bf16_t, true>), dim3((unsigned)T), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, count, gout, (bf16_t *)dlogits, ld_d);
+    else hipLaunchKernelGGL((ce_bwd_rows_k<bf16_t, false>), dim3((unsigned)T), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, count, gout, (bf16_t *)dlogits, ld_d);
+  } else {
+    return LDM_E_DTYPE;
+  }
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}

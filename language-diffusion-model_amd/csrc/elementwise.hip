@@ -1,0 +1,565 @@
+// HBM-bound row kernels: embedding gather / scatter-add, RMSNorm fwd/bwd, RoPE,
+// SwiGLU, column sums, casts.  All move 8-16 B per lane per access.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ embedding
+// One wave per token row; lanes sweep the row in 4-element vectors.
+template <typename TO>
+__global__ __launch_bounds__(256) void embed_fwd_k(const int64_t *ids, const float *table,
+                                                   int64_t T, int64_t d, int64_t vocab, TO *out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < T; t += nwaves) {
+    int64_t id = ids[t];
+    const bool ok = (id >= 0) & (id < vocab);
+    const float *src = table + (ok ? id : 0) * d;
+    TO *dst = out + t * d;
+    for (int64_t c = lane * 4; c < d; c += 256) {
+      f4 v = ld4(src + c);
+      if (!ok) v = f4{{0.f, 0.f, 0.f, 0.f}};
+      st4(dst + c, v);
+    }
+  }
+}
+
+// Scatter-add of dout rows into dtable.  Each block owns ROWS consecutive tokens.
+// Rows whose id == hot_id (the mask token: about half of all rows in a training
+// step) are first summed in registers across the block's tokens and added with
+// one atomic per column per block; other rows go straight to float atomics
+// (256 contiguous bytes per wave-instruction).
+template <typename TI, int ROWS>
+__global__ __launch_bounds__(256) void embed_bwd_k(const int64_t *ids, const TI *dout, int64_t T,
+                                                   int64_t d, int64_t vocab, int64_t hot_id,
+                                                   float *dtable) {
+  const int64_t t0 = (int64_t)blockIdx.x * ROWS;
+  const int64_t t1 = (t0 + ROWS < T) ? t0 + ROWS : T;
+  for (int64_t c = threadIdx.x; c < d; c += blockDim.x) {
+    float hot = 0.f;
+    bool any_hot = false;
+    for (int64_t t = t0; t < t1; ++t) {
+      const int64_t id = ids[t];          // wave-uniform: served from one cache line
+      const float g = Elt<TI>::ld(dout + t * d + c);
+      if (id == hot_id) {
+        hot += g;
+        any_hot = true;
+      } else if (id >= 0 && id < vocab) {
+        atomicAdd(dtable + id * d + c, g);
+      }
+    }
+    if (any_hot && hot_id >= 0 && hot_id < vocab) atomicAdd(dtable + hot_id * d + c, hot);
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm
+// One wave per row.  NV = 4-element vectors per lane held in registers.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T *x, const float *w, int64_t rows,
+                                                     int d, float eps, T *y, float *rstd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = d >> 2;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const T *xr = x + r * d;
+    f4 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        v[i] = ld4(xr + vi * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss = fmaf(v[i].v[j], v[i].v[j], ss);
+      }
+    }
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)d + eps);
+    if (lane == 0) rstd[r] = rs;
+    T *yr = y + r * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        f4 g = ld4(w + vi * 4);
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = g.v[j] * (v[i].v[j] * rs);
+        st4(yr + vi * 4, o);
+      }
+    }
+  }
+}
+
+// Backward: each wave walks a strided set of rows, keeps its dw partial sums in
+// registers, then the block's 4 waves are reduced through LDS and the block writes
+// one row of dw_partial[gridDim.x][d].
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T *x, const float *w, const float *rstd,
+                                                     const T *dy, const T *dres, int64_t rows, int d,
+                                                     T *dx, float *dw_partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][d]
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = d >> 2;
+  f4 wv[NV], acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = lane + i * 64;
+    acc[i] = f4{{0.f, 0.f, 0.f, 0.f}};
+    wv[i] = (vi < nvec) ? ld4(w + vi * 4) : f4{{0.f, 0.f, 0.f, 0.f}};
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const T *xr = x + r * d;
+    const T *gr = dy + r * d;
+    const float rs = rstd[r];
+    f4 xv[NV], gv[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        xv[i] = ld4(xr + vi * 4);
+        gv[i] = ld4(gr + vi * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i].v[j] = fmaf(gv[i].v[j], xv[i].v[j] * rs, acc[i].v[j]);
+          gv[i].v[j] *= wv[i].v[j];
+          dot = fmaf(gv[i].v[j], xv[i].v[j], dot);
+        }
+      }
+    }
+    dot = wave_sum(dot);
+    const float k = dot * rs * rs * rs * inv_d;
+    T *dr = dx + r * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = fmaf(rs, gv[i].v[j], -xv[i].v[j] * k);
+        if (dres) {
+          f4 rr = ld4(dres + r * d + vi * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o.v[j] += rr.v[j];
+        }
+        st4(dr + vi * 4, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) st4(smem + wid * d + vi * 4, acc[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    dw_partial[(int64_t)blockIdx.x * d + c] = smem[c] + smem[d + c] + smem[2 * d + c] + smem[3 * d + c];
+}
+
+// out[c] = sum_p partial[p][c]   (deterministic second stage)
+__global__ __launch_bounds__(256) void reduce_partials_k(const float *partial, int64_t nparts, int64_t d,
+                                                         float *out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < nparts; ++p) s += partial[p * d + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------ RoPE on fused qkv
+// One thread per (row, head, pair-vector): rotates element i with i + hd/2.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_qk_k(T *qkv, int64_t rows, int64_t seq, int nhead, int hd,
+                                                 int64_t ld, const float *cos_t, const float *sin_t,
+                                                 float q_scale, int inverse) {
+  const int half = hd >> 1;
+  const int vec_per_head = half >> 2;            // 4 pairs per thread
+  const int64_t per_row = (int64_t)2 * nhead * vec_per_head;   // q heads then k heads
+  const int64_t total = rows * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / per_row;
+    int rem = (int)(idx - row * per_row);
+    const int which = rem / (nhead * vec_per_head);   // 0 = q, 1 = k
+    rem -= which * nhead * vec_per_head;
+    const int h = rem / vec_per_head;
+    const int i0 = (rem - h * vec_per_head) * 4;
+    const int64_t pos = row % seq;
+    T *p = qkv + row * ld + (int64_t)which * nhead * hd + (int64_t)h * hd + i0;
+    f4 a = ld4(p), b = ld4(p + half);
+    f4 c = ld4(cos_t + pos * half + i0), s = ld4(sin_t + pos * half + i0);
+    const float sc = which == 0 ? q_scale : 1.0f;
+    f4 oa, ob;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!inverse) {
+        oa.v[j] = (a.v[j] * c.v[j] - b.v[j] * s.v[j]) * sc;
+        ob.v[j] = (b.v[j] * c.v[j] + a.v[j] * s.v[j]) * sc;
+      } else {
+        oa.v[j] = (a.v[j] * c.v[j] + b.v[j] * s.v[j]) * sc;
+        ob.v[j] = (b.v[j] * c.v[j] - a.v[j] * s.v[j]) * sc;
+      }
+    }
+    st4(p, oa);
+    st4(p + half, ob);
+  }
+}
+
+// scalar form for head dims whose half is not a multiple of 4
+template <typename T>
+__global__ __launch_bounds__(256) void rope_qk_scalar_k(T *qkv, int64_t rows, int64_t seq, int nhead,
+                                                        int hd, int64_t ld, const float *cos_t,
+                                                        const float *sin_t, float q_scale, int inverse) {
+  const int half = hd >> 1;
+  const int64_t per_row = (int64_t)2 * nhead * half;
+  const int64_t total = rows * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / per_row;
+    int rem = (int)(idx - row * per_row);
+    const int which = rem / (nhead * half);
+    rem -= which * nhead * half;
+    const int h = rem / half;
+    const int i = rem - h * half;
+    const int64_t pos = row % seq;
+    T *p = qkv + row * ld + (int64_t)which * nhead * hd + (int64_t)h * hd + i;
+    const float a = Elt<T>::ld(p), b = Elt<T>::ld(p + half);
+    const float c = cos_t[pos * half + i], s = sin_t[pos * half + i];
+    const float sc = which == 0 ? q_scale : 1.0f;
+    float oa, ob;
+    if (!inverse) {
+      oa = (a * c - b * s) * sc;
+      ob = (b * c + a * s) * sc;
+    } else {
+      oa = (a * c + b * s) * sc;
+      ob = (b * c - a * s) * sc;
+    }
+    Elt<T>::st(p, oa);
+    Elt<T>::st(p + half, ob);
+  }
+}
+
+// ------------------------------------------------------------------ SwiGLU
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_k(const T *ag, int64_t rows, int64_t F, T *h) {
+  const int64_t vec_per_row = F >> 2;
+  const int64_t total = rows * vec_per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / vec_per_row;
+    const int64_t c = (idx - r * vec_per_row) * 4;
+    f4 a = ld4(ag + r * 2 * F + c), g = ld4(ag + r * 2 * F + F + c);
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-g.v[j]));
+      o.v[j] = a.v[j] * (g.v[j] * sg);
+    }
+    st4(h + r * F + c, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_k(const T *ag, const T *dh, int64_t rows, int64_t F,
+                                                    T *dag) {
+  const int64_t vec_per_row = F >> 2;
+  const int64_t total = rows * vec_per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / vec_per_row;
+    const int64_t c = (idx - r * vec_per_row) * 4;
+    f4 a = ld4(ag + r * 2 * F + c), g = ld4(ag + r * 2 * F + F + c), d = ld4(dh + r * F + c);
+    f4 da, dg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-g.v[j]));
+      da.v[j] = d.v[j] * (g.v[j] * sg);
+      dg.v[j] = d.v[j] * a.v[j] * sg * (1.0f + g.v[j] * (1.0f - sg));
+    }
+    st4(dag + r * 2 * F + c, da);
+    st4(dag + r * 2 * F + F + c, dg);
+  }
+}
+
+// ------------------------------------------------------------------ column sums
+// Block (64 x 4): thread x owns one column, 4 row lanes; grid.y slices the rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T *X, int64_t M, int64_t N, int64_t ld,
+                                                int64_t rows_per_slice, float *partial) {
+  __shared__ float sm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t r1 = (r0 + rows_per_slice < M) ? r0 + rows_per_slice : M;
+  float s = 0.f;
+  if (c < N)
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += Elt<T>::ld(X + r * ld + c);
+  sm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < N) partial[(int64_t)blockIdx.y * N + c] = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_k(const float *src, bf16_t *dst, int64_t n4,
+                                                       int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x)
+    st4(dst + i * 4, ld4(src + i * 4));
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) dst[i] = f32_to_bf16(src[i]);
+}
+
+inline unsigned stream_grid(int64_t work_items, int per_block) {
+  int64_t b = ceil_div(work_items, per_block);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline int rms_nv(int64_t d) {
+  const int64_t need = ceil_div(d / 4, 64);
+  int nv = 1;
+  while (nv < need) nv <<= 1;
+  return nv;
+}
+
+constexpr int kRmsBwdBlocks = 512;   // rows of the dw partial workspace
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" int ldm_embed_fwd(const int64_t *ids, const float *table, int64_t T, int64_t d,
+                             int64_t vocab, void *out, int out_dtype, void *stream) {
+  if (T < 0 || d <= 0 || vocab <= 0) return LDM_E_BADARG;
+  if (T == 0) return LDM_OK;
+  if (!ids || !table || !out) return LDM_E_BADARG;
+  if (d % 4) return LDM_E_SHAPE;
+  if (!aligned_to(table, 16) || !aligned_to(out, 16)) return LDM_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = stream_grid(T, 4);
+  if (out_dtype == LDM_F32)
+    hipLaunchKernelGGL(embed_fwd_k<float>, dim3(grid), dim3(256), 0, s, ids, table, T, d, vocab, (float *)out);
+  else if (out_dtype == LDM_BF16)
+    hipLaunchKernelGGL(embed_fwd_k<bf16_t>, dim3(grid), dim3(256), 0, s, ids, table, T, d, vocab, (bf16_t *)out);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_embed_bwd(const int64_t *ids, const void *dout, int dtype, int64_t T, int64_t d,
+                             int64_t vocab, int64_t hot_id, float *dtable, void *stream) {
+  if (T < 0 || d <= 0 || vocab <= 0) return LDM_E_BADARG;
+  if (T == 0) return LDM_OK;
+  if (!ids || !dout || !dtable) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int ROWS = 32;
+  const unsigned grid = (unsigned)ceil_div(T, ROWS);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL((embed_bwd_k<float, ROWS>), dim3(grid), dim3(256), 0, s, ids, (const float *)dout, T, d, vocab, hot_id, dtable);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((embed_bwd_k<bf16_t, ROWS>), dim3(grid), dim3(256), 0, s, ids, (const bf16_t *)dout, T, d, vocab, hot_id, dtable);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <typename T>
+static int rmsnorm_fwd_launch(const void *x, const float *w, int64_t rows, int64_t d, float eps, void *y,
+                              float *rstd, hipStream_t s) {
+  const unsigned grid = stream_grid(rows, 4);
+  const T *xx = (const T *)x;
+  T *yy = (T *)y;
+#define RMS_F(NV) hipLaunchKernelGGL((rmsnorm_fwd_k<T, NV>), dim3(grid), dim3(256), 0, s, xx, w, rows, (int)d, eps, yy, rstd)
+  switch (rms_nv(d)) {
+    case 1: RMS_F(1); break;
+    case 2: RMS_F(2); break;
+    case 4: RMS_F(4); break;
+    case 8: RMS_F(8); break;
+    case 16: RMS_F(16); break;
+    case 32: RMS_F(32); break;
+    default: return LDM_E_SHAPE;
+  }
+#undef RMS_F
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_rmsnorm_fwd(const void *x, const float *w, int64_t T, int64_t d, float eps, int dtype,
+                               void *y, float *rstd, void *stream) {
+  if (T < 0 || d <= 0) return LDM_E_BADARG;
+  if (T == 0) return LDM_OK;
+  if (!x || !w || !y || !rstd) return LDM_E_BADARG;
+  if (d % 4 || d > 8192) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(y, 16) || !aligned_to(w, 16)) return LDM_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_F32) return rmsnorm_fwd_launch<float>(x, w, T, d, eps, y, rstd, s);
+  if (dtype == LDM_BF16) return rmsnorm_fwd_launch<bf16_t>(x, w, T, d, eps, y, rstd, s);
+  return LDM_E_DTYPE;
+}
+
+extern "C" int64_t ldm_rmsnorm_bwd_ws_floats(int64_t T, int64_t d) {
+  (void)T;
+  return (int64_t)kRmsBwdBlocks * d;
+}
+
+template <typename T>
+static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, const void *dy,
+                              const void *dres, int64_t rows, int64_t d, void *dx, float *dw,
+                              float *dw_partial, hipStream_t s) {
+  int64_t blocks = ceil_div(rows, 4);
+  if (blocks > kRmsBwdBlocks) blocks = kRmsBwdBlocks;
+  const unsigned grid = (unsigned)blocks;
+  const size_t lds = (size_t)4 * d * sizeof(float);
+#define RMS_B(NV)                                                                                      \
+  hipLaunchKernelGGL((rmsnorm_bwd_k<T, NV>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,      \
+                     (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial)
+  switch (rms_nv(d)) {
+    case 1: RMS_B(1); break;
+    case 2: RMS_B(2); break;
+    case 4: RMS_B(4); break;
+    case 8: RMS_B(8); break;
+    case 16: RMS_B(16); break;
+    case 32: RMS_B(32); break;
+    default: return LDM_E_SHAPE;
+  }
+#undef RMS_B
+  LDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, s, dw_partial,
+                     (int64_t)grid, d, dw);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd, const void *dy,
+                               const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,
+                               float *dw_partial, void *stream) {
+  if (T < 0 || d <= 0) return LDM_E_BADARG;
+  if (!dw) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 0) return (int)hipMemsetAsync(dw, 0, d * sizeof(float), s);
+  if (!x || !w || !rstd || !dy || !dx || !dw_partial) return LDM_E_BADARG;
+  if (d % 4 || d > 8192) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(dy, 16) || !aligned_to(dx, 16) || !aligned_to(w, 16) ||
+      (dres && !aligned_to(dres, 16)))
+    return LDM_E_ALIGN;
+  if (dtype == LDM_F32) return rmsnorm_bwd_launch<float>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s);
+  if (dtype == LDM_BF16) return rmsnorm_bwd_launch<bf16_t>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s);
+  return LDM_E_DTYPE;
+}
+
+extern "C" int ldm_rope_qk(void *qkv, int dtype, int64_t batch, int64_t seq, int64_t nhead, int64_t hd,
+                           int64_t ld, const float *cos_t, const float *sin_t, float q_scale, int inverse,
+                           void *stream) {
+  if (batch < 0 || seq < 0 || nhead <= 0 || hd <= 0) return LDM_E_BADARG;
+  const int64_t rows = batch * seq;
+  if (rows == 0) return LDM_OK;
+  if (!qkv || !cos_t || !sin_t) return LDM_E_BADARG;
+  if (hd % 2 || ld < 3 * nhead * hd) return LDM_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t half = hd / 2;
+  const size_t esz = dtype == LDM_F32 ? 4 : 2;
+  const bool vec = (half % 4 == 0) && (ld % 4 == 0) && aligned_to(qkv, 16) && aligned_to(cos_t, 16) &&
+                   aligned_to(sin_t, 16) && ((half * esz) % (4 * esz) == 0);
+  if (dtype != LDM_F32 && dtype != LDM_BF16) return LDM_E_DTYPE;
+  if (vec) {
+    const unsigned grid = stream_grid(rows * 2 * nhead * (half / 4), 256);
+    if (dtype == LDM_F32)
+      hipLaunchKernelGGL(rope_qk_k<float>, dim3(grid), dim3(256), 0, s, (float *)qkv, rows, seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+    else
+      hipLaunchKernelGGL(rope_qk_k<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t *)qkv, rows, seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+  } else {
+    const unsigned grid = stream_grid(rows * 2 * nhead * half, 256);
+    if (dtype == LDM_F32)
+      hipLaunchKernelGGL(rope_qk_scalar_k<float>, dim3(grid), dim3(256), 0, s, (float *)qkv, rows, seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+    else
+      hipLaunchKernelGGL(rope_qk_scalar_k<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t *)qkv, rows, seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+  }
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_swiglu_fwd(const void *ag, int64_t T, int64_t F, int dtype, void *h, void *stream) {
+  if (T < 0 || F <= 0) return LDM_E_BADARG;
+  if (T == 0) return LDM_OK;
+  if (!ag || !h) return LDM_E_BADARG;
+  if (F % 4) return LDM_E_SHAPE;
+  if (!aligned_to(ag, 16) || !aligned_to(h, 16)) return LDM_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = stream_grid(T * (F / 4), 256);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(swiglu_fwd_k<float>, dim3(grid), dim3(256), 0, s, (const float *)ag, T, F, (float *)h);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(swiglu_fwd_k<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)ag, T, F, (bf16_t *)h);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_swiglu_bwd(const void *ag, const void *dh, int64_t T, int64_t F, int dtype, void *dag,
+                              void *stream) {
+  if (T < 0 || F <= 0) return LDM_E_BADARG;
+  if (T == 0) return LDM_OK;
+  if (!ag || !dh || !dag) return LDM_E_BADARG;
+  if (F % 4) return LDM_E_SHAPE;
+  if (!aligned_to(ag, 16) || !aligned_to(dh, 16) || !aligned_to(dag, 16)) return LDM_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = stream_grid(T * (F / 4), 256);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(swiglu_bwd_k<float>, dim3(grid), dim3(256), 0, s, (const float *)ag, (const float *)dh, T, F, (float *)dag);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(swiglu_bwd_k<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)ag, (const bf16_t *)dh, T, F, (bf16_t *)dag);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+static inline int64_t colsum_slices(int64_t M) {
+  int64_t sl = ceil_div(M, 512);
+  if (sl > 256) sl = 256;
+  if (sl < 1) sl = 1;
+  return sl;
+}
+
+extern "C" int64_t ldm_colsum_ws_floats(int64_t M, int64_t N) { return colsum_slices(M) * N; }
+
+extern "C" int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
+                          void *stream) {
+  if (M < 0 || N <= 0 || !out) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (M == 0) return (int)hipMemsetAsync(out, 0, N * sizeof(float), s);
+  if (!X || !ws) return LDM_E_BADARG;
+  const int64_t slices = colsum_slices(M);
+  const int64_t rps = ceil_div(M, slices);
+  dim3 grid((unsigned)ceil_div(N, 64), (unsigned)slices);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(colsum_k<float>, grid, dim3(256), 0, s, (const float *)X, M, N, ld, rps, ws);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(colsum_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, M, N, ld, rps, ws);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, ws, slices, N, out);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream) {
+  if (n < 0) return LDM_E_BADARG;
+  if (n == 0) return LDM_OK;
+  if (!src || !dst) return LDM_E_BADARG;
+  if (!aligned_to(src, 16) || !aligned_to(dst, 8)) return LDM_E_ALIGN;
+  hipLaunchKernelGGL(cast_f32_bf16_k, dim3(stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t *)dst, n / 4, n);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}

@@ -1,0 +1,14 @@
+// Internal GEMM entry points shared by the C-ABI dispatcher and the attention code.
+#pragma once
+#include "common.h"
+
+// exact-fp32-accumulate FMA kernel, any strides / alignment / batch
+int ldm_gemm_generic(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                     float alpha, const void *A, int64_t lda, ldm_bstride sa, const void *B, int64_t ldb,
+                     ldm_bstride sb, void *C, int64_t ldc, ldm_bstride sc, const float *bias, const void *R,
+                     int64_t ldr, int64_t batch, int64_t batch_inner, hipStream_t s);
+
+// bf16 MFMA kernel; returns LDM_E_SHAPE / LDM_E_ALIGN when the problem does not fit it
+int ldm_gemm_mfma_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                       const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
+                       const float *bias, const void *R, int64_t ldr, hipStream_t s);

@@ -1,0 +1,48 @@
+// C-ABI GEMM dispatch: bf16 problems that fit the MFMA kernel run there, everything
+// else (F32 parity mode, odd shapes, batched attention products) on the FMA kernel.
+#include "common.h"
+#include "gemm.h"
+
+extern "C" int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                        float alpha, const void *A, int64_t lda, const void *B, int64_t ldb, void *C,
+                        int64_t ldc, const float *bias, const void *R, int64_t ldr, void *stream) {
+  if (M < 0 || N < 0 || K < 0) return LDM_E_BADARG;
+  if (M == 0 || N == 0) return LDM_OK;
+  if (!C || (K > 0 && (!A || !B))) return LDM_E_BADARG;
+  if (in_dtype != LDM_F32 && in_dtype != LDM_BF16) return LDM_E_DTYPE;
+  if (out_dtype != LDM_F32 && out_dtype != LDM_BF16) return LDM_E_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == LDM_BF16) {
+    const int rc = ldm_gemm_mfma_bf16(out_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias,
+                                      R, ldr, s);
+    if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
+  }
+  const ldm_bstride z{0, 0};
+  return ldm_gemm_generic(in_dtype, out_dtype, transA, transB, M, N, K, alpha, A, lda, z, B, ldb, z, C, ldc, z,
+                          bias, R, ldr, 1, 1, s);
+}
+
+extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N,
+                                int64_t K, float alpha, const void *A, int64_t lda, ldm_bstride sa,
+                                const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,
+                                ldm_bstride sc, int64_t batch, int64_t batch_inner, void *stream) {
+  if (M < 0 || N < 0 || K < 0 || batch < 0) return LDM_E_BADARG;
+  if (M == 0 || N == 0 || batch == 0) return LDM_OK;
+  if (!C || (K > 0 && (!A || !B))) return LDM_E_BADARG;
+  return ldm_gemm_generic(in_dtype, out_dtype, transA, transB, M, N, K, alpha, A, lda, sa, B, ldb, sb, C, ldc,
+                          sc, nullptr, nullptr, 0, batch, batch_inner, (hipStream_t)stream);
+}
+
+extern "C" int ldm_abi_version(void) { return 1; }
+
+extern "C" const char *ldm_error_string(int code) {
+  switch (code) {
+    case LDM_OK: return "ok";
+    case LDM_E_BADARG: return "bad argument (null pointer or negative size)";
+    case LDM_E_ALIGN: return "pointer or leading dimension not aligned";
+    case LDM_E_SHAPE: return "shape not supported by the kernels";
+    case LDM_E_DTYPE: return "unknown element type";
+    case LDM_E_WORKSPACE: return "workspace too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}

@@ -1,0 +1,106 @@
+"""ctypes binding of ``libldm_hip.so`` (the C ABI declared in ``include/ldm_hip.h``).
+
+There is no CPU fallback: if the library is missing, or a tensor handed to an
+op is not on a ROCm device, the call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
+
+F32, BF16 = 0, 1
+DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+_vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
+
+
+class BStride(C.Structure):
+    _fields_ = [("outer", C.c_int64), ("inner", C.c_int64)]
+
+
+# name -> (restype, argtypes); kept in sync with include/ldm_hip.h
+SIGNATURES = {
+    "ldm_abi_version": (_i32, []),
+    "ldm_error_string": (C.c_char_p, [_i32]),
+    "ldm_mask_fwd": (_i32, [_vp, _vp, _i32, _f32, _vp, _f32, _i64, _i64, _i64, _i64, _i64, _i64, _u64, _u64,
+                            _vp, _vp, _vp]),
+    "ldm_embed_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "ldm_embed_bwd": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "ldm_rmsnorm_fwd": (_i32, [_vp, _vp, _i64, _i64, _f32, _i32, _vp, _vp, _vp]),
+    "ldm_rmsnorm_bwd_ws_floats": (_i64, [_i64, _i64]),
+    "ldm_rmsnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ldm_rope_qk": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _f32, _i32, _vp]),
+    "ldm_swiglu_fwd": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "ldm_swiglu_bwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "ldm_gemm": (_i32, [_i32, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64,
+                        _vp, _vp, _i64, _vp]),
+    "ldm_gemm_batched": (_i32, [_i32, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, BStride, _vp, _i64,
+                                BStride, _vp, _i64, BStride, _i64, _i64, _vp]),
+    "ldm_colsum_ws_floats": (_i64, [_i64, _i64]),
+    "ldm_colsum": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "ldm_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "ldm_attn_saved_bytes": (_i64, [_i32, _i64, _i64, _i64, _i64]),
+    "ldm_attn_bwd_ws_bytes": (_i64, [_i32, _i64, _i64, _i64, _i64]),
+    "ldm_attn_fwd": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "ldm_attn_bwd": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "ldm_ce_fwd": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
+                          _vp, _vp, _vp]),
+    "ldm_ce_bwd": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
+                          _vp, _vp, _i64, _vp]),
+    "ldm_softmax_rows_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ldm_softmax_bwd_rows_f32": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C language-diffusion-model_amd`). There is no fallback path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ldm_error_string(rc).decode()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "this operator runs only on a ROCm device (HIP kernels, no CPU fallback); "
+                f"got a tensor on {t.device}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return DTYPE_CODE[dt]
+    except KeyError:
+        raise TypeError(f"unsupported compute dtype {dt}; use torch.float32 or torch.bfloat16") from None

@@ -1,0 +1,178 @@
+"""Data-parallel gradient synchronisation: bucketed all-reduce overlapped with backward.
+
+Stands in for what the reference gets from ``Accelerator().prepare(model, ...)``
+(main.py:105-108 -> torch DistributedDataParallel, 25 MiB buckets) and
+``accelerator.backward(loss)`` (src/trainer.py:74,136).  One process per GPU;
+``torch.distributed`` backend ``nccl`` (RCCL over xGMI on ROCm) or ``gloo`` (CPU).
+
+Semantics kept from DDP: every rank ends backward with grad = mean over ranks of
+its local gradients (each rank's loss is normalised by ITS OWN masked count).
+
+Mechanics:
+  * parameters are assigned to flat fp32 buckets in REVERSE registration order
+    (LM head and final norm first, embedding last), the order backward produces them;
+  * a post-accumulate hook copies each finished gradient into its bucket slice and
+    repoints ``param.grad`` at the slice; when a bucket's last gradient arrives its
+    all-reduce is launched asynchronously (RCCL's own stream), so communication of
+    late layers overlaps the backward of early ones;
+  * an engine callback queued on the first hook waits for all buckets at the end of
+    backward and applies the 1/world_size scaling; parameters that produced no
+    gradient contribute zeros so that ranks stay in lock-step.
+Buckets default to 64 MiB: xGMI is point-to-point, a ring step is bound by one
+~153 GB/s link and has a fixed latency per collective, so fewer/larger collectives
+than DDP's 25 MiB are the better trade on one MI355X node.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.autograd import Variable
+
+
+class _Bucket:
+    def __init__(self, params, device):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.offsets = {}
+        off = 0
+        for p in params:
+            self.offsets[p] = off
+            off += p.numel()
+        self.pending = len(params)
+        self.ready = set()
+        self.work = None
+
+    def view_for(self, p):
+        off = self.offsets[p]
+        return self.flat[off:off + p.numel()].view_as(p)
+
+
+class GradBucketDataParallel(nn.Module):
+    def __init__(self, module: nn.Module, process_group=None, bucket_bytes: int = 64 << 20):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        self._buckets: list[_Bucket] = []
+        self._bucket_of = {}
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._add_bucket(cur)
+        self._callback_queued = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        # identical starting point on every rank (DDP broadcasts rank 0's state too)
+        if self.world_size > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                               group=process_group)
+
+    def _add_bucket(self, params):
+        b = _Bucket(list(params), params[0].device)
+        self._buckets.append(b)
+        for p in params:
+            self._bucket_of[p] = b
+
+    # attribute passthrough: the trainer reads model.tokenizer, calls model.train()/eval()
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("module"), name)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    @property
+    def num_buckets(self) -> int:
+        return len(self._buckets)
+
+    def _on_grad(self, p):
+        if self.world_size == 1:
+            return
+        if not self._callback_queued:
+            Variable._execution_engine.queue_callback(self._finalize)
+            self._callback_queued = True
+        b = self._bucket_of[p]
+        if p in b.ready:          # a second accumulation into the same grad in one backward
+            return
+        view = b.view_for(p)
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+        b.ready.add(p)
+        if len(b.ready) == len(b.params):
+            self._launch(b)
+
+    def _launch(self, b):
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+
+    def _finalize(self):
+        self._callback_queued = False
+        for b in self._buckets:
+            if b.work is None:
+                # some parameters produced no gradient this step: they contribute zeros
+                for p in b.params:
+                    if p not in b.ready:
+                        view = b.view_for(p)
+                        view.zero_()
+                        p.grad = view
+                self._launch(b)
+        inv = 1.0 / self.world_size
+        for b in self._buckets:
+            b.work.wait()
+            b.flat.mul_(inv)
+            b.work = None
+            b.ready.clear()
+
+    def finish_grad_sync(self):
+        """Explicit form of the end-of-backward callback (idempotent)."""
+        if self._callback_queued:
+            self._finalize()
+
+
+class HipAccelerator:
+    """The small part of ``accelerate.Accelerator`` that the training step touches.
+
+    ``prepare`` moves modules to this rank's GPU, selects the compute dtype
+    (``mixed_precision="bf16"`` is what the reference's Accelerate config would
+    request) and wraps the model for gradient all-reduce when more than one rank is
+    running; ``backward`` is ``loss.backward()`` (accelerate/accelerator.py backward
+    with gradient_accumulation_steps == 1)."""
+
+    def __init__(self, mixed_precision: str = "no", device=None, bucket_bytes: int = 64 << 20):
+        self.mixed_precision = mixed_precision
+        self.bucket_bytes = bucket_bytes
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        self.num_processes = dist.get_world_size() if dist.is_initialized() else 1
+        self.process_index = dist.get_rank() if dist.is_initialized() else 0
+        self.is_main_process = self.process_index == 0
+
+    def prepare(self, *objs):
+        out = []
+        for o in objs:
+            if isinstance(o, nn.Module):
+                o = o.to(self.device)
+                dtype = torch.bfloat16 if self.mixed_precision == "bf16" else torch.float32
+                for m in o.modules():
+                    if hasattr(m, "set_compute_dtype"):
+                        m.set_compute_dtype(dtype)
+                if self.num_processes > 1:
+                    o = GradBucketDataParallel(o, bucket_bytes=self.bucket_bytes)
+            out.append(o)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def backward(self, loss, **kwargs):
+        loss.backward(**kwargs)

@@ -1,0 +1,45 @@
+"""Model wrapper of the masked-diffusion training step.
+
+Mirrors ``DiffusionLanguageModel.__init__`` / ``forward`` of the reference
+(src/model.py:22-72): draw t, mask, run the transformer, return
+``(logits, masked_input_ids, mask_indices)``.  ``generate`` / ``sample`` are
+reverse-process inference and are not part of this package.
+"""
+
+from __future__ import annotations
+
+import random
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+
+class DiffusionLanguageModel(nn.Module):
+    def __init__(self, transformer, tokenizer, masking_strategy, remasking_strategy=None) -> None:
+        super().__init__()
+        self.transformer = transformer
+        self.tokenizer = tokenizer
+        self.masking_strategy = masking_strategy
+        self.remasking_strategy = remasking_strategy
+
+    def forward(self, input_ids: Tensor, attention_mask: Tensor | None = None,
+                t: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor]:
+        # src/model.py:59-64: one python-RNG scalar per call unless t is given; a
+        # one-element tensor is unwrapped, anything else is passed through.
+        if t is None:
+            mask_prob = random.random()
+        else:
+            mask_prob = t.item() if (isinstance(t, torch.Tensor) and t.numel() == 1) else t
+        masked_input_ids, mask_indices = self.masking_strategy.apply_random_mask(
+            input_ids=input_ids, mask_prob=mask_prob)
+        logits = self.transformer(input_ids=masked_input_ids, attention_mask=attention_mask)
+        return logits, masked_input_ids, mask_indices
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError("reverse-process generation (src/model.py:74-106) is outside the "
+                                  "training-step scope of this package")
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError("reverse-process sampling (src/model.py:108-189) is outside the "
+                                  "training-step scope of this package")

@@ -1,0 +1,373 @@
+"""Autograd operators over the HIP kernels.
+
+Each ``torch.autograd.Function`` here owns its save-for-backward state and calls
+the C ABI with raw device pointers on torch's current stream.  PyTorch only
+provides device memory, streams and the autograd tape.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import Tensor
+
+from . import _native as N
+
+PAD_N = 64  # output columns of a projection are padded to this multiple in memory
+
+# data_ptr -> row stride of the gradient buffer most recently produced by the masked-CE
+# backward: its rows are padded to PAD_N columns and the padding is zero, so the
+# projection backward can consume it in place.
+_ZERO_PADDED: dict[int, int] = {}
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _rows2d(x: Tensor) -> Tensor:
+    """[..., C] -> [rows, C] view with unit column stride (copies only if needed)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+        x2 = x2.contiguous()
+    return x2
+
+
+# ----------------------------------------------------------------------------
+# weight shadows: compute-dtype copies of the fp32 master parameters, packed so
+# that projections sharing an input run as ONE GEMM.  Rebuilt when a parameter's
+# version counter moves (i.e. after every optimizer step).
+# ----------------------------------------------------------------------------
+class PackedWeights:
+    def __init__(self, weights, biases, dtype: torch.dtype):
+        self.weights = list(weights)
+        self.biases = list(biases)
+        self.dtype = dtype
+        self.n_each = [int(w.shape[0]) for w in self.weights]
+        self.n = sum(self.n_each)
+        self.k = int(self.weights[0].shape[1])
+        self.n_pad = _round_up(self.n, PAD_N)
+        self._key = None
+        self.w = None
+        self.b = None
+
+    def get(self):
+        key = tuple((p._version, p.data_ptr()) for p in self.weights + self.biases)
+        if key != self._key or self.w is None or self.w.device != self.weights[0].device:
+            dev = self.weights[0].device
+            if self.w is None or self.w.device != dev:
+                self.w = torch.zeros(self.n_pad, self.k, dtype=self.dtype, device=dev)
+                self.b = torch.zeros(self.n_pad, dtype=torch.float32, device=dev)
+            off = 0
+            for wt, bs, n in zip(self.weights, self.biases, self.n_each):
+                wd = wt.detach()
+                if self.dtype == torch.bfloat16:
+                    if not wd.is_contiguous():
+                        wd = wd.contiguous()
+                    N.check(N.lib().ldm_cast_f32_to_bf16(wd.data_ptr(), self.w[off:off + n].data_ptr(),
+                                                         wd.numel(), N.stream()), "ldm_cast_f32_to_bf16")
+                else:
+                    self.w[off:off + n].copy_(wd)
+                self.b[off:off + n].copy_(bs.detach())
+                off += n
+            self._key = key
+        return self.w, self.b
+
+
+def _gemm(in_dt, out_dt, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, res=None, ldr=0, alpha=1.0):
+    N.check(N.lib().ldm_gemm(N.dtype_code(in_dt), N.dtype_code(out_dt), ta, tb, m, n, k, alpha,
+                             a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
+                             N.ptr(bias), N.ptr(res), ldr, N.stream()), "ldm_gemm")
+
+
+class _PackedLinear(torch.autograd.Function):
+    """y[T, n] = x[T, k] @ Wpacked^T + b (+ residual);  grads for every packed weight/bias."""
+
+    @staticmethod
+    def forward(ctx, x2, residual, pack: PackedWeights, *params):
+        N.require_device(x2)
+        w, b = pack.get()
+        T, k = x2.shape
+        dt = pack.dtype
+        if x2.dtype != dt:
+            x2 = x2.to(dt)
+        y = torch.empty(T, pack.n_pad, dtype=dt, device=x2.device)
+        res = None
+        if residual is not None:
+            res = _rows2d(residual)
+            if res.dtype != dt:
+                res = res.to(dt)
+        _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
+              res=res, ldr=res.stride(0) if res is not None else 0)
+        ctx.pack = pack
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x2, w)
+        return y[:, :pack.n] if pack.n != pack.n_pad else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        pack = ctx.pack
+        dt = pack.dtype
+        T, k = x2.shape
+        n, n_pad = pack.n, pack.n_pad
+        # gradient with the padded row stride and zero padding columns
+        row_ok = gy.dtype == dt and gy.stride(-1) == 1 and (T == 1 or gy.stride(0) == n_pad)
+        if row_ok and (n_pad == n or _ZERO_PADDED.pop(gy.data_ptr(), None) == n_pad):
+            g = gy
+        else:
+            g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
+            g[:, :n].copy_(gy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, k, dtype=dt, device=g.device)
+            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k)
+        dw = torch.empty(n_pad, k, dtype=torch.float32, device=g.device)
+        _gemm(dt, torch.float32, 1, 0, n_pad, k, T, g, n_pad, x2, x2.stride(0), dw, k)
+        db = torch.empty(n_pad, dtype=torch.float32, device=g.device)
+        ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
+        N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
+                                   ws.data_ptr(), N.stream()), "ldm_colsum")
+        grads_w, grads_b = [], []
+        off = 0
+        for ne in pack.n_each:
+            grads_w.append(dw[off:off + ne])
+            grads_b.append(db[off:off + ne])
+            off += ne
+        dres = gy if ctx.has_res else None
+        return (dx, dres, None, *grads_w, *grads_b)
+
+
+def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None) -> Tensor:
+    shape = x.shape
+    x2 = _rows2d(x)
+    y = _PackedLinear.apply(x2, residual, pack, *pack.weights, *pack.biases)
+    return y.reshape(*shape[:-1], pack.n) if y.is_contiguous() else y.view(*shape[:-1], pack.n)
+
+
+# ----------------------------------------------------------------------------
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, out_dtype, hot_id):
+        N.require_device(ids, table)
+        ids_c = ids.contiguous()
+        T = ids_c.numel()
+        V, d = table.shape
+        out = torch.empty(*ids.shape, d, dtype=out_dtype, device=table.device)
+        tb = table.detach()
+        if not tb.is_contiguous():
+            tb = tb.contiguous()
+        N.check(N.lib().ldm_embed_fwd(ids_c.data_ptr(), tb.data_ptr(), T, d, V, out.data_ptr(),
+                                      N.dtype_code(out_dtype), N.stream()), "ldm_embed_fwd")
+        ctx.save_for_backward(ids_c)
+        ctx.shape = (V, d)
+        ctx.hot_id = hot_id
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids_c,) = ctx.saved_tensors
+        V, d = ctx.shape
+        g = g.contiguous()
+        dtab = torch.zeros(V, d, dtype=torch.float32, device=g.device)
+        N.check(N.lib().ldm_embed_bwd(ids_c.data_ptr(), g.data_ptr(), N.dtype_code(g.dtype), ids_c.numel(), d, V,
+                                      ctx.hot_id, dtab.data_ptr(), N.stream()), "ldm_embed_bwd")
+        return None, dtab, None, None
+
+
+def embedding(ids: Tensor, table: Tensor, out_dtype: torch.dtype, hot_id: int = 103) -> Tensor:
+    return _Embedding.apply(ids, table, out_dtype, hot_id)
+
+
+# ----------------------------------------------------------------------------
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        N.require_device(x, weight)
+        xc = x.contiguous()
+        d = xc.shape[-1]
+        T = xc.numel() // d
+        y = torch.empty_like(xc)
+        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+        w = weight.detach().float().contiguous()
+        N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
+                                        y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+        ctx.save_for_backward(xc, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, w, rstd = ctx.saved_tensors
+        d = xc.shape[-1]
+        T = xc.numel() // d
+        g = gy.contiguous()
+        if g.dtype != xc.dtype:
+            g = g.to(xc.dtype)
+        dx = torch.empty_like(xc)
+        dw = torch.empty(d, dtype=torch.float32, device=xc.device)
+        ws = torch.empty(N.lib().ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
+        N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), None, T, d,
+                                        N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                        N.stream()), "ldm_rmsnorm_bwd")
+        return dx, dw, None
+
+
+def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
+    return _RMSNorm.apply(x, weight, eps)
+
+
+# ----------------------------------------------------------------------------
+class _SwiGLUAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ag):
+        N.require_device(ag)
+        ag = ag.contiguous()
+        F2 = ag.shape[-1]
+        F = F2 // 2
+        T = ag.numel() // F2
+        h = torch.empty(*ag.shape[:-1], F, dtype=ag.dtype, device=ag.device)
+        N.check(N.lib().ldm_swiglu_fwd(ag.data_ptr(), T, F, N.dtype_code(ag.dtype), h.data_ptr(), N.stream()),
+                "ldm_swiglu_fwd")
+        ctx.save_for_backward(ag)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        (ag,) = ctx.saved_tensors
+        F2 = ag.shape[-1]
+        F = F2 // 2
+        T = ag.numel() // F2
+        g = gh.contiguous()
+        if g.dtype != ag.dtype:
+            g = g.to(ag.dtype)
+        dag = torch.empty_like(ag)
+        N.check(N.lib().ldm_swiglu_bwd(ag.data_ptr(), g.data_ptr(), T, F, N.dtype_code(ag.dtype), dag.data_ptr(),
+                                       N.stream()), "ldm_swiglu_bwd")
+        return dag
+
+
+def swiglu_act(ag: Tensor) -> Tensor:
+    """h = a * silu(g) for the fused activation ag = [a | g] (w1 branch | w2 branch)."""
+    return _SwiGLUAct.apply(ag)
+
+
+# ----------------------------------------------------------------------------
+class _RopeAttention(torch.autograd.Function):
+    """RoPE(q,k), q/sqrt(hd), softmax(q k^T + key mask) v on a fused qkv activation."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin):
+        N.require_device(qkv)
+        lib = N.lib()
+        dt = qkv.dtype
+        code = N.dtype_code(dt)
+        D = H * hd
+        qkv = qkv.contiguous() if qkv.stride(-1) != 1 else qkv
+        q2 = qkv.reshape(B * S, 3 * D)
+        if q2.data_ptr() != qkv.data_ptr() or q2.stride(0) != 3 * D:
+            q2 = q2.contiguous()
+        # the rotation is applied in place; the pre-rotation values are not needed again
+        # (the projection's backward uses only its own input and weights)
+        N.check(lib.ldm_rope_qk(q2.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
+                                1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
+        o = torch.empty(B * S, D, dtype=dt, device=qkv.device)
+        saved = torch.empty(lib.ldm_attn_saved_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
+        N.check(lib.ldm_attn_fwd(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
+                                 saved.data_ptr(), N.stream()), "ldm_attn_fwd")
+        ctx.save_for_backward(q2, o, saved, cos, sin)
+        ctx.key_valid = key_valid
+        ctx.dims = (B, S, H, hd)
+        return o.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, go):
+        q2, o, saved, cos, sin = ctx.saved_tensors
+        B, S, H, hd = ctx.dims
+        D = H * hd
+        lib = N.lib()
+        dt = q2.dtype
+        code = N.dtype_code(dt)
+        g = go.reshape(B * S, D)
+        if g.dtype != dt:
+            g = g.to(dt)
+        g = g.contiguous()
+        dqkv = torch.empty_like(q2)
+        ws = torch.empty(lib.ldm_attn_bwd_ws_bytes(code, B, H, S, hd), dtype=torch.uint8, device=q2.device)
+        N.check(lib.ldm_attn_bwd(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                 g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), N.stream()),
+                "ldm_attn_bwd")
+        N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
+                                1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
+        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None
+
+
+def rope_attention(qkv: Tensor, key_valid: Tensor | None, B: int, S: int, H: int, hd: int, cos: Tensor,
+                   sin: Tensor) -> Tensor:
+    return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin)
+
+
+# ----------------------------------------------------------------------------
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode):
+        N.require_device(logits)
+        lib = N.lib()
+        V = logits.shape[-1]
+        l2 = logits.reshape(-1, V)
+        if l2.stride(-1) != 1 or l2.dtype not in N.DTYPE_CODE:
+            l2 = l2.float().contiguous() if l2.dtype not in N.DTYPE_CODE else l2.contiguous()
+        T = l2.shape[0]
+        seq = logits.shape[-2] if logits.dim() >= 2 else 1
+        dev = logits.device
+        tg = targets.reshape(-1).contiguous()
+        mi = masked_ids.reshape(-1).contiguous() if masked_ids is not None else None
+        mb = mask_bool.reshape(-1).contiguous().view(torch.uint8) if mask_bool is not None else None
+        av = att_valid.reshape(-1).contiguous().view(torch.uint8) if att_valid is not None else None
+        sw = seq_weight.reshape(-1).float().contiguous() if seq_weight is not None else None
+        lse = torch.empty(T, dtype=torch.float32, device=dev)
+        tmp = torch.empty(T, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        ld = l2.stride(0) if T > 1 else max(V, l2.stride(0))
+        N.check(lib.ldm_ce_fwd(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(), N.ptr(mi),
+                               int(mask_token_id), N.ptr(mb), N.ptr(av), N.ptr(sw), norm_mode, lse.data_ptr(),
+                               tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), N.stream()), "ldm_ce_fwd")
+        ctx.save_for_backward(l2, tg, lse, out)
+        ctx.aux = (mi, mb, av, sw, int(mask_token_id), norm_mode, seq, ld, logits.shape, logits.dtype)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        l2, tg, lse, out = ctx.saved_tensors
+        mi, mb, av, sw, mask_token_id, norm_mode, seq, ld, shape, in_dtype = ctx.aux
+        lib = N.lib()
+        T, V = l2.shape
+        Vp = _round_up(V, PAD_N)
+        dl = torch.empty(T, Vp, dtype=l2.dtype, device=l2.device)
+        g = gout.reshape(1).float().contiguous()
+        N.check(lib.ldm_ce_bwd(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(), N.ptr(mi),
+                               mask_token_id, N.ptr(mb), N.ptr(av), N.ptr(sw), norm_mode, lse.data_ptr(),
+                               out[1:2].data_ptr(), g.data_ptr(), dl.data_ptr(), Vp, N.stream()), "ldm_ce_bwd")
+        d = dl[:, :V] if Vp != V else dl
+        d = d.view(*shape[:-1], V) if d.is_contiguous() else torch.as_strided(
+            dl, tuple(shape), _padded_strides(shape, Vp))
+        if d.dtype != in_dtype:
+            d = d.to(in_dtype)
+        else:
+            _ZERO_PADDED.clear()
+            _ZERO_PADDED[dl.data_ptr()] = Vp
+        return d, None, None, None, None, None, None, None
+
+
+def _padded_strides(shape, ld):
+    strides = [1] * len(shape)
+    acc = ld
+    for i in range(len(shape) - 2, -1, -1):
+        strides[i] = acc
+        acc *= shape[i]
+    return tuple(strides)
+
+
+def masked_ce(logits, targets, *, masked_ids=None, mask_token_id=0, mask_bool=None, att_valid=None,
+              seq_weight=None, norm_mode=0) -> Tensor:
+    return _MaskedCE.apply(logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode)

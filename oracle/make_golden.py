@@ -1,0 +1,249 @@
+"""Generate golden vectors from the real reference and pin the oracle to it.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container, where the reference
+checkout is importable (``/root/reference``); the reference itself never
+travels, only the ``.npz`` data written under ``tests/golden/`` does.
+
+    python oracle/make_golden.py [--reference /root/reference]
+
+For every case it (1) runs the reference's own modules
+(DiffusionLanguageModel.forward -> variational_lower_bound_loss -> backward),
+(2) runs ``oracle/step_oracle.py`` on the same weights / ids / t / draw and
+asserts agreement (masking bit-exact, loss+grads <= 1e-6 rel in fp32),
+(3) stores inputs and expected outputs.
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _load_oracle():
+    spec = importlib.util.spec_from_file_location("step_oracle", os.path.join(HERE, "step_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["step_oracle"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _rel(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def build_case(ref, so, name, *, d, H, L, Fd, V, B, S, t, seed, ragged, dirty, out_dir):
+    from src.loss import variational_lower_bound_loss
+    from src.masking_strategy import create_masking_strategy, create_remasking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+
+    torch.manual_seed(seed)
+    cfg = DiffusionTransformerConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L,
+                                     dim_feedforward=Fd, dropout=0.0, layer_norm_eps=1e-12,
+                                     max_position_embeddings=512)
+    tr = DiffusionTransformer(cfg)
+    # Perturb the RMSNorm gains and give biases some size so that every
+    # parameter's gradient path is exercised (ones would hide a missing gain).
+    with torch.no_grad():
+        for n, p_ in tr.named_parameters():
+            if n.endswith("norm1.weight") or n.endswith("norm2.weight") or n == "norm.weight":
+                p_.add_(0.1 * torch.randn_like(p_))
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    ms = create_masking_strategy("random", 101, 102, 0, 103)
+    rs = create_remasking_strategy("random", 101, 102, 0, 103)
+    model = DiffusionLanguageModel(tr, tok, ms, rs)
+    model.train()
+
+    ids, att = so.synthetic_batch(B, S, V, seed=seed + 1, ragged=ragged, dirty=dirty)
+    draw_seed = seed + 2
+    torch.manual_seed(draw_seed)
+    draw = torch.rand(ids.shape, dtype=torch.float32)
+
+    results = {}
+    for mode in ("fp32", "bf16"):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(draw_seed)
+        if mode == "bf16":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                logits, masked, mask = model(input_ids=ids, attention_mask=att, t=torch.tensor([t]))
+            logits = logits.float()
+        else:
+            logits, masked, mask = model(input_ids=ids, attention_mask=att, t=torch.tensor([t]))
+        loss = variational_lower_bound_loss(logits=logits, targets=ids, masked_input_ids=masked,
+                                            attention_mask=att, mask_token_id=103)
+        loss.backward()
+        grads = {n: p_.grad.detach().clone() for n, p_ in tr.named_parameters()}
+        results[mode] = (loss.detach(), grads, masked, mask, logits.detach())
+
+    # the injected draw reproduces the reference's mask exactly
+    t32 = float(torch.tensor([t]).item())
+    om, omask = so.forward_mask(ids, t32, draw)
+    assert torch.equal(om, results["fp32"][2]) and torch.equal(omask, results["fp32"][3]), "mask draw not reproduced"
+
+    # pin the oracle to the reference
+    params = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+    ocfg = so.OracleConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd,
+                           layer_norm_eps=1e-12)
+    for mode in ("fp32", "bf16"):
+        ol, og, omk, omsk, ologits = so.step_loss_and_grads(params, ocfg, ids, att, t32, draw,
+                                                            autocast_bf16=(mode == "bf16"))
+        rl, rg, rmk, rmsk, rlogits = results[mode]
+        assert torch.equal(omk, rmk) and torch.equal(omsk, rmsk)
+        tol = 1e-6 if mode == "fp32" else 1e-6
+        assert _rel(ol, rl) <= tol, (name, mode, "loss", _rel(ol, rl))
+        assert _rel(ologits, rlogits) <= tol, (name, mode, "logits", _rel(ologits, rlogits))
+        for k in rg:
+            e = _rel(og[k], rg[k])
+            # k_proj.bias has a mathematically zero gradient (softmax shift invariance)
+            if "k_proj.bias" in k:
+                assert float((og[k] - rg[k]).abs().max()) < 1e-6
+            else:
+                assert e <= tol, (name, mode, k, e)
+        print(f"[{name}/{mode}] oracle == reference   loss={float(rl):.6f}  M={int(rmsk.sum())}")
+
+    out = {
+        "cfg": np.array([V, d, H, L, Fd], dtype=np.int64),
+        "input_ids": ids.numpy(), "attention_mask": att.numpy(),
+        "t": np.array([t32], dtype=np.float32), "draw": draw.numpy(),
+        "masked_input_ids": results["fp32"][2].numpy(),
+        "mask_indices": results["fp32"][3].numpy(),
+        "logits_fp32": results["fp32"][4].numpy(),
+        "loss_fp32": results["fp32"][0].numpy(), "loss_bf16": results["bf16"][0].numpy(),
+    }
+    for k, v in params.items():
+        out["param/" + k] = v.numpy()
+    for k, v in results["fp32"][1].items():
+        out["grad_fp32/" + k] = v.numpy()
+    for k, v in results["bf16"][1].items():
+        out["grad_bf16/" + k] = v.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(out_dir, f"step_{name}.npz"), **out)
+
+
+def build_masking(so, out_dir):
+    """Known answers of tests/test_masking_strategy.py:7-49 plus seeded draws
+    pushed through the reference's RandomMaskingStrategy."""
+    from src.masking_strategy import RandomMaskingStrategy
+
+    st = RandomMaskingStrategy(bos_token_id=101, eos_token_id=102, pad_token_id=0, mask_token_id=103)
+    ka_ids = torch.tensor([[101, 450, 231, 102, 0], [101, 450, 231, 450, 102]])
+    m1, i1 = st.apply_random_mask(ka_ids, mask_prob=1.0)
+    m0, i0 = st.apply_random_mask(ka_ids, mask_prob=0.0)
+    exp = torch.tensor([[False, True, True, False, False], [False, True, True, True, False]])
+    assert torch.equal(i1, exp) and torch.equal(m0, ka_ids) and not i0.any()
+    out = {"ka_ids": ka_ids.numpy(), "ka_masked_p1": m1.numpy(), "ka_mask_p1": i1.numpy(),
+           "ka_masked_p0": m0.numpy(), "ka_mask_p0": i0.numpy()}
+    for j, (B, S, p, seed) in enumerate([(4, 33, 0.3, 7), (7, 129, 0.77, 8), (2, 1024, 0.5, 9),
+                                         (1, 1, 0.5, 10), (5, 64, 0.999999, 11)]):
+        ids, _ = so.synthetic_batch(B, S, 30522, seed=seed, ragged=S > 8, dirty=S > 8)
+        torch.manual_seed(seed)
+        masked, mask = st.apply_random_mask(ids, mask_prob=p)
+        torch.manual_seed(seed)
+        draw = torch.rand(ids.shape, dtype=torch.float32)
+        if j == 2:
+            # draws sitting exactly on the fp32-rounded threshold must not mask
+            draw[0, 10] = float(np.float32(p))
+            draw[0, 11] = float(np.nextafter(np.float32(p), np.float32(0)))
+            masked, mask = so.forward_mask(ids, p, draw)
+            chk_m = ids.clone()
+            elig = (ids != 101) & (ids != 102) & (ids != 0)
+            ref_mask = (draw < p) & elig          # torch semantics, reference line 111
+            chk_m[ref_mask] = 103
+            assert torch.equal(chk_m, masked) and torch.equal(ref_mask, mask)
+        om, omask = so.forward_mask(ids, p, draw)
+        assert torch.equal(om, masked) and torch.equal(omask, mask)
+        out[f"r{j}_ids"] = ids.numpy()
+        out[f"r{j}_p"] = np.array([p], dtype=np.float64)
+        out[f"r{j}_draw"] = draw.numpy()
+        out[f"r{j}_masked"] = masked.numpy()
+        out[f"r{j}_mask"] = mask.numpy()
+    np.savez_compressed(os.path.join(out_dir, "masking.npz"), **out)
+    print("[masking] oracle == reference on known answers and 5 seeded cases")
+
+
+def build_loss(so, out_dir):
+    """tests/test_loss.py:29-67 fixture values through the reference loss, a
+    large-vocab case, an attention-masked case and the empty-mask case."""
+    from src.loss import masked_cross_entropy_loss, variational_lower_bound_loss
+
+    out = {}
+    torch.manual_seed(42)
+    B, S, V = 2, 5, 150
+    logits = torch.randn(B, S, V)
+    targets = torch.randint(0, V - 100, (B, S))
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[:, 1] = True
+    mask[:, 3] = True
+    mids = targets.clone()
+    mids[mask] = 103
+    att = torch.ones(B, S)
+    att2 = att.clone()
+    att2[:, 3] = 0
+    lg = logits.clone().requires_grad_(True)
+    l_mce = masked_cross_entropy_loss(lg, targets, mask)
+    l_mce.backward()
+    out.update(t_logits=logits.numpy(), t_targets=targets.numpy(), t_mask=mask.numpy(),
+               t_masked_ids=mids.numpy(), t_att=att.numpy(), t_att2=att2.numpy(),
+               t_loss_mce=l_mce.detach().numpy(), t_grad_mce=lg.grad.numpy(),
+               t_loss_vlb=variational_lower_bound_loss(logits, targets, mids, 103).detach().numpy(),
+               t_loss_vlb_att=variational_lower_bound_loss(logits, targets, mids, 103, att).detach().numpy(),
+               t_loss_vlb_att2=variational_lower_bound_loss(logits, targets, mids, 103, att2).detach().numpy(),
+               t_loss_empty=masked_cross_entropy_loss(logits, targets, torch.zeros_like(mask)).detach().numpy())
+    assert float(out["t_loss_empty"]) == 0.0
+    assert abs(float(so.masked_ce(logits, targets, mask)) - float(l_mce)) < 1e-7
+
+    g = torch.Generator().manual_seed(5)
+    B, S, V = 2, 6, 30522
+    logits = torch.randn(B, S, V, generator=g) * 3.0
+    targets = torch.randint(0, V, (B, S), generator=g)
+    mids = targets.clone()
+    mids[0, 1] = 103
+    mids[0, 4] = 103
+    mids[1, 2] = 103
+    mids[1, 5] = 103
+    att = torch.ones(B, S, dtype=torch.int64)
+    att[1, 5] = 0
+    lg = logits.clone().requires_grad_(True)
+    lv = variational_lower_bound_loss(lg, targets, mids, 103, att)
+    lv.backward()
+    rows = (mids == 103) & (att == 1)
+    out.update(v_logits=logits.numpy(), v_targets=targets.numpy(), v_masked_ids=mids.numpy(),
+               v_att=att.numpy(), v_loss=lv.detach().numpy(),
+               v_grad_rows=lg.grad[rows].numpy(), v_rows=rows.numpy())
+    assert abs(float(so.vlb_loss(logits, targets, mids, 103, att)) - float(lv)) < 1e-6
+    np.savez_compressed(os.path.join(out_dir, "loss.npz"), **out)
+    print("[loss] oracle == reference on the reference-test fixture and a V=30522 case")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    args = ap.parse_args()
+    so = _load_oracle()
+    # the reference's package is called ``src``; import it from ITS checkout
+    sys.path = [args.reference] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+    os.chdir(args.reference)
+    os.makedirs(args.out, exist_ok=True)
+    build_masking(so, args.out)
+    build_loss(so, args.out)
+    build_case(None, so, "c1_tiny", d=32, H=4, L=2, Fd=64, V=200, B=3, S=10, t=0.6, seed=42,
+               ragged=True, dirty=True, out_dir=args.out)
+    build_case(None, so, "hd96", d=192, H=2, L=1, Fd=128, V=300, B=2, S=48, t=0.5, seed=7,
+               ragged=True, dirty=True, out_dir=args.out)
+    build_case(None, so, "nomask_att", d=64, H=2, L=2, Fd=96, V=256, B=2, S=70, t=0.35, seed=11,
+               ragged=False, dirty=False, out_dir=args.out)
+
+
+if __name__ == "__main__":
+    main()

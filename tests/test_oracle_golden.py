@@ -1,0 +1,60 @@
+"""The CPU oracle reproduces the reference-generated golden vectors (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import step_oracle as so
+
+
+def test_masking_known_answers_and_seeded_cases():
+    g = load_golden("masking.npz")
+    ids = torch.from_numpy(g["ka_ids"])
+    # reference tests/test_masking_strategy.py:22-49: p=1 masks every eligible token, p=0 none
+    m, i = so.forward_mask(ids, 1.0, torch.rand(ids.shape))
+    assert np.array_equal(m.numpy(), g["ka_masked_p1"]) and np.array_equal(i.numpy(), g["ka_mask_p1"])
+    m, i = so.forward_mask(ids, 0.0, torch.rand(ids.shape))
+    assert np.array_equal(m.numpy(), g["ka_masked_p0"]) and not i.any()
+    for j in range(5):
+        ids = torch.from_numpy(g[f"r{j}_ids"])
+        m, i = so.forward_mask(ids, float(g[f"r{j}_p"][0]), torch.from_numpy(g[f"r{j}_draw"]))
+        assert np.array_equal(m.numpy(), g[f"r{j}_masked"]), j
+        assert np.array_equal(i.numpy(), g[f"r{j}_mask"]), j
+
+
+def test_loss_golden():
+    g = load_golden("loss.npz")
+    logits = torch.from_numpy(g["t_logits"])
+    targets = torch.from_numpy(g["t_targets"])
+    assert abs(float(so.masked_ce(logits, targets, torch.from_numpy(g["t_mask"]))) - float(g["t_loss_mce"])) < 1e-6
+    mids = torch.from_numpy(g["t_masked_ids"])
+    assert abs(float(so.vlb_loss(logits, targets, mids, 103)) - float(g["t_loss_vlb"])) < 1e-6
+    assert abs(float(so.vlb_loss(logits, targets, mids, 103, torch.from_numpy(g["t_att2"]))) - float(g["t_loss_vlb_att2"])) < 1e-6
+    assert float(so.masked_ce(logits, targets, torch.zeros(2, 5, dtype=torch.bool))) == 0.0
+    lv = so.vlb_loss(torch.from_numpy(g["v_logits"]), torch.from_numpy(g["v_targets"]),
+                     torch.from_numpy(g["v_masked_ids"]), 103, torch.from_numpy(g["v_att"]))
+    assert abs(float(lv) - float(g["v_loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["c1_tiny", "hd96", "nomask_att"])
+def test_step_golden(name):
+    g = load_golden(f"step_{name}.npz")
+    V, d, H, L, Fd = [int(x) for x in g["cfg"]]
+    cfg = so.OracleConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd)
+    params = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    ids = torch.from_numpy(g["input_ids"])
+    att = torch.from_numpy(g["attention_mask"])
+    for mode in ("fp32", "bf16"):
+        loss, grads, masked, mask, logits = so.step_loss_and_grads(
+            params, cfg, ids, att, float(g["t"][0]), torch.from_numpy(g["draw"]), autocast_bf16=(mode == "bf16"))
+        assert np.array_equal(masked.numpy(), g["masked_input_ids"])
+        assert np.array_equal(mask.numpy(), g["mask_indices"])
+        assert rel_err(loss, g[f"loss_{mode}"]) < 1e-6
+        if mode == "fp32":
+            assert rel_err(logits, g["logits_fp32"]) < 1e-6
+        for k, v in grads.items():
+            ref = g[f"grad_{mode}/{k}"]
+            if "k_proj.bias" in k:
+                assert float(np.abs(v.numpy() - ref).max()) < 1e-6
+            else:
+                assert rel_err(v, ref) < 2e-6, (mode, k)
