@@ -1,0 +1,197 @@
+"""Masked-diffusion training-step benchmark (one process per GPU).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is the reference trainer's step (src/trainer.py:119-140 of the reference):
+zero_grad -> forward masking -> transformer forward -> masked CE -> backward (with bucketed
+RCCL gradient all-reduce when N > 1) -> AdamW.step -> loss.item(), on synthetic tokens that are
+resident in HBM before the timed region.  Workload: the reference's configs/default.yaml model
+(d=768, 8 heads of 96, 8 layers, ff=1024, vocab 30522) at sequence length 512, bf16 compute,
+dropout 0.0, per-GPU batch --batch (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+import types
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (spec), per GPU
+PEAK_HBM_GBS = 8000.0       # MI355X HBM3E peak (spec), per GPU
+
+CONFIGS = {
+    # reference configs/default.yaml:8-15 with len(BertTokenizer) = 30522
+    "default": dict(vocab_size=30522, d_model=768, nhead=8, num_layers=8, dim_feedforward=1024),
+    "1b": dict(vocab_size=32000, d_model=2048, nhead=16, num_layers=16, dim_feedforward=5632),
+    "tiny": dict(vocab_size=200, d_model=64, nhead=2, num_layers=2, dim_feedforward=128),
+}
+
+
+def train_flops_per_token(c, seq):
+    """3 * (2*N_mm + 4*S*d*L), N_mm = L*(4d^2 + 3dF) + d*V: the algorithmic matmul+attention work."""
+    d, L, Fd, V = c["d_model"], c["num_layers"], c["dim_feedforward"], c["vocab_size"]
+    n_mm = L * (4 * d * d + 3 * d * Fd) + d * V
+    return 3.0 * (2.0 * n_mm + 4.0 * seq * d * L)
+
+
+def synthetic_tokens(batch, seq, vocab, seed):
+    g = torch.Generator().manual_seed(seed)
+    lo = 1000 if vocab > 2000 else 110
+    ids = torch.randint(lo, vocab, (batch, seq), generator=g, dtype=torch.int64)
+    ids[:, 0] = 101
+    ids[:, -1] = 102
+    return ids, torch.ones(batch, seq, dtype=torch.int64)
+
+
+def cpu_baseline(cfg, seq, steps=3):
+    """The CPU restatement of the reference step (oracle/step_oracle.py: fp32, torch CPU ops,
+    autograd backward, AdamW) on a bounded sample: B=4 sequences per step."""
+    from oracle import step_oracle as so
+    ncores = os.cpu_count() or 1
+    threads = min(ncores, int(os.environ.get("OMP_NUM_THREADS", ncores)))
+    torch.set_num_threads(threads)
+    ocfg = so.OracleConfig(vocab_size=cfg["vocab_size"], d_model=cfg["d_model"], nhead=cfg["nhead"],
+                           num_layers=cfg["num_layers"], dim_feedforward=cfg["dim_feedforward"])
+    params = {k: v.requires_grad_(True) for k, v in so.init_params(ocfg, seed=42).items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=5e-4, weight_decay=0.1)
+    B = 4
+    ids, att = synthetic_tokens(B, seq, cfg["vocab_size"], 1234)
+    rng = random.Random(42)
+    g = torch.Generator().manual_seed(7)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        masked, _ = so.forward_mask(ids, rng.random(), torch.rand(ids.shape, generator=g))
+        logits = so.transformer_forward(params, ocfg, masked, att)
+        loss = so.vlb_loss(logits, ids, masked, 103, att)
+        if loss.grad_fn is not None:
+            loss.backward()
+        opt.step()
+        float(loss)
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B * seq / med, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed steps (median) of B={B}, S={seq}, fp32, oracle/step_oracle.py + AdamW"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="default", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from src import ops
+    from src.dp import HipAccelerator
+    from src.masking_strategy import create_masking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.trainer import DiffusionLanguageModelTrainer
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+
+    cfg = CONFIGS[args.config]
+    torch.manual_seed(42)
+    random.seed(42)     # the reference seeds both identically on every rank (main.py:39-40)
+    tr = DiffusionTransformer(DiffusionTransformerConfig(dropout=0.0, layer_norm_eps=1e-12,
+                                                         max_position_embeddings=max(512, args.seq), **cfg))
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
+    acc = HipAccelerator(mixed_precision="bf16" if args.dtype == "bf16" else "no", device=dev,
+                         bucket_bytes=args.bucket_mb << 20)
+    model = acc.prepare(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
+    trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+    model.train()
+
+    ids, att = synthetic_tokens(args.batch, args.seq, cfg["vocab_size"], 1234 + rank)
+    batch = {"input_ids": ids.to(dev), "attention_mask": att.to(dev)}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = 0.0
+    for _ in range(args.warmup):
+        last = trainer._step(batch).item()
+    sync()
+    ops.GEMM_EVENTS = {"head.fwd": []}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = trainer._step(batch).item()
+    sync()
+    elapsed = time.perf_counter() - t0
+    events = ops.GEMM_EVENTS["head.fwd"]
+    ops.GEMM_EVENTS = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        tokens = args.batch * args.seq * world * args.steps
+        tps = tokens / elapsed
+        fpt = train_flops_per_token(cfg, args.seq)
+        # dominant kernel: the LM-head forward GEMM ([B*S, d] x [d, V]), one launch per step
+        ms = [a.elapsed_time(b) for a, b, _ in events]
+        flops = events[0][2] if events else 0.0
+        avg_ms = sum(ms) / max(len(ms), 1)
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "masked-diffusion train tokens/sec (node)", "value": tps, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs/default.yaml model, seq {args.seq}" if args.config == "default"
+                       else f"{args.config} model, seq {args.seq}",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": args.seq,
+                       "parallelism": f"dp{world}", "dropout": 0.0, "optimizer": "AdamW(lr=5e-4, wd=0.1)",
+                       **cfg},
+            "loss_last_step": last,
+            "train_flops_per_token": fpt,
+            "mfma_fraction_of_step": tps * fpt / (world * PEAK_BF16_TFLOPS * 1e12),
+            "roofline": {"kernel": "gemm_mfma_k (LM-head forward GEMM)", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops, "avg_launch_ms": avg_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.seq)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

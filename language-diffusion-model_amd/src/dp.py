@@ -70,6 +70,7 @@ class GradBucketDataParallel(nn.Module):
         if cur:
             self._add_bucket(cur)
         self._callback_queued = False
+        self._next = 0
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         # identical starting point on every rank (DDP broadcasts rank 0's state too)
         if self.world_size > 1:
@@ -111,23 +112,30 @@ class GradBucketDataParallel(nn.Module):
             view.copy_(p.grad)
             p.grad = view
         b.ready.add(p)
-        if len(b.ready) == len(b.params):
-            self._launch(b)
+        self._launch_ready()
 
-    def _launch(self, b):
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+    def _launch_ready(self):
+        # Collectives must be issued in the same order on every rank: bucket i+1 is launched
+        # only after bucket i, whatever order the gradients arrive in on this rank.
+        while self._next < len(self._buckets):
+            b = self._buckets[self._next]
+            if len(b.ready) != len(b.params):
+                break
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._next += 1
 
     def _finalize(self):
         self._callback_queued = False
-        for b in self._buckets:
-            if b.work is None:
-                # some parameters produced no gradient this step: they contribute zeros
-                for p in b.params:
-                    if p not in b.ready:
-                        view = b.view_for(p)
-                        view.zero_()
-                        p.grad = view
-                self._launch(b)
+        for b in self._buckets[self._next:]:
+            # parameters that produced no gradient this step contribute zeros
+            for p in b.params:
+                if p not in b.ready:
+                    view = b.view_for(p)
+                    view.zero_()
+                    p.grad = view
+                    b.ready.add(p)
+        self._launch_ready()
+        self._next = 0
         inv = 1.0 / self.world_size
         for b in self._buckets:
             b.work.wait()

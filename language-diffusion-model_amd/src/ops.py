@@ -40,7 +40,8 @@ def _rows2d(x: Tensor) -> Tensor:
 # version counter moves (i.e. after every optimizer step).
 # ----------------------------------------------------------------------------
 class PackedWeights:
-    def __init__(self, weights, biases, dtype: torch.dtype):
+    def __init__(self, weights, biases, dtype: torch.dtype, name: str = "linear"):
+        self.name = name
         self.weights = list(weights)
         self.biases = list(biases)
         self.dtype = dtype
@@ -75,10 +76,24 @@ class PackedWeights:
         return self.w, self.b
 
 
-def _gemm(in_dt, out_dt, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, res=None, ldr=0, alpha=1.0):
+# Optional per-launch timing for the benchmark: when set to a dict, every GEMM whose tag is a
+# key gets a pair of events recorded around its launch on the launching stream; the list
+# under the key collects (start, end, flops) triples.
+GEMM_EVENTS: dict | None = None
+
+
+def _gemm(in_dt, out_dt, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, res=None, ldr=0, alpha=1.0,
+          tag=None):
+    ev = GEMM_EVENTS.get(tag) if (GEMM_EVENTS is not None and tag is not None) else None
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     N.check(N.lib().ldm_gemm(N.dtype_code(in_dt), N.dtype_code(out_dt), ta, tb, m, n, k, alpha,
                              a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
                              N.ptr(bias), N.ptr(res), ldr, N.stream()), "ldm_gemm")
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, 2.0 * m * n * k))
 
 
 class _PackedLinear(torch.autograd.Function):
@@ -99,9 +114,9 @@ class _PackedLinear(torch.autograd.Function):
             if res.dtype != dt:
                 res = res.to(dt)
         _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
-              res=res, ldr=res.stride(0) if res is not None else 0)
+              res=res, ldr=res.stride(0) if res is not None else 0, tag=pack.name + ".fwd")
         ctx.pack = pack
-        ctx.has_res = residual is not None
+        ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.save_for_backward(x2, w)
         return y[:, :pack.n] if pack.n != pack.n_pad else y
 
@@ -122,9 +137,9 @@ class _PackedLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, k, dtype=dt, device=g.device)
-            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k)
+            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag=pack.name + ".dx")
         dw = torch.empty(n_pad, k, dtype=torch.float32, device=g.device)
-        _gemm(dt, torch.float32, 1, 0, n_pad, k, T, g, n_pad, x2, x2.stride(0), dw, k)
+        _gemm(dt, torch.float32, 1, 0, n_pad, k, T, g, n_pad, x2, x2.stride(0), dw, k, tag=pack.name + ".dw")
         db = torch.empty(n_pad, dtype=torch.float32, device=g.device)
         ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
         N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
@@ -135,7 +150,7 @@ class _PackedLinear(torch.autograd.Function):
             grads_w.append(dw[off:off + ne])
             grads_b.append(db[off:off + ne])
             off += ne
-        dres = gy if ctx.has_res else None
+        dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
         return (dx, dres, None, *grads_w, *grads_b)
 
 

@@ -81,9 +81,9 @@ class SwiGLU(nn.Module):
         if key not in self._packs:
             if which == "in":
                 self._packs[key] = ops.PackedWeights([self.w1.weight, self.w2.weight],
-                                                     [self.w1.bias, self.w2.bias], self.compute_dtype)
+                                                     [self.w1.bias, self.w2.bias], self.compute_dtype, "w12")
             else:
-                self._packs[key] = ops.PackedWeights([self.w3.weight], [self.w3.bias], self.compute_dtype)
+                self._packs[key] = ops.PackedWeights([self.w3.weight], [self.w3.bias], self.compute_dtype, "w3")
         return self._packs[key]
 
     def forward(self, x: Tensor, residual: Tensor | None = None) -> Tensor:
@@ -117,7 +117,7 @@ class RotaryPositionEmbedding(nn.Module):
         if (self.cached_seq_len != seq_len or self.cached_cos is None
                 or self.cached_cos.device != x.device):
             self.cached_seq_len = seq_len
-            t = torch.arange(seq_len, device=x.device).type_as(self.inv_freq)
+            t = torch.arange(seq_len, device=x.device, dtype=self.inv_freq.dtype)
             freqs = torch.einsum("i,j->ij", t, self.inv_freq.to(x.device))
             emb = torch.cat((freqs, freqs), dim=-1)
             self.cached_cos = emb.cos()
@@ -169,10 +169,10 @@ class RotaryMultiheadAttention(nn.Module):
             if which == "qkv":
                 self._packs[key] = ops.PackedWeights(
                     [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
-                    [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], self.compute_dtype)
+                    [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], self.compute_dtype, "qkv")
             else:
                 self._packs[key] = ops.PackedWeights([self.out_proj.weight], [self.out_proj.bias],
-                                                     self.compute_dtype)
+                                                     self.compute_dtype, "out")
         return self._packs[key]
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Tensor | None = None,
@@ -270,7 +270,7 @@ class DiffusionTransformer(nn.Module):
     def _head_pack(self) -> ops.PackedWeights:
         key = self.compute_dtype
         if key not in self._packs:
-            self._packs[key] = ops.PackedWeights([self.output_layer.weight], [self.output_layer.bias], key)
+            self._packs[key] = ops.PackedWeights([self.output_layer.weight], [self.output_layer.bias], key, "head")
         return self._packs[key]
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:
