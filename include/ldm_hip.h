@@ -115,6 +115,13 @@ typedef struct {
 int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
              float alpha, const void *A, int64_t lda, const void *B, int64_t ldb, void *C,
              int64_t ldc, const float *bias, const void *R, int64_t ldr, void *stream);
+/* Accumulating form for weight gradients: C(fp32)[M,N] += alpha * opA(A) * opB(B).  BF16
+ * problems split the K range over workgroups (float atomics into C), so a small output
+ * with a long reduction (K = number of tokens) still fills the chip; the sum order, and so
+ * the last bits, can differ between runs.  F32 problems accumulate in a fixed order. */
+int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                 void *stream);
 int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N,
                      int64_t K, float alpha, const void *A, int64_t lda, ldm_bstride sa,
                      const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,

@@ -239,27 +239,6 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
   }
 }
 
-// --------------------------------------------------------------------------- delta
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-__global__ __launch_bounds__(256) void attn_delta_k(FArgs a) {
-  const int64_t total = (int64_t)a.B * a.S * a.H;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = idx / a.H;
-    const int head = (int)(idx - row * a.H);
-    const bf16_t *o = a.o_in + row * a.ld_o + (int64_t)head * a.hd;
-    const bf16_t *g = a.dout + row * a.ld_o + (int64_t)head * a.hd;
-    float s = 0.f;
-    for (int d = 0; d < a.hd; d += 4) {
-      const f4 x = ld4(o + d), y = ld4(g + d);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s = fmaf(x.v[j], y.v[j], s);
-    }
-    const int64_t bb = row / a.S, qq = row - bb * a.S;
-    a.delta[(bb * a.H + head) * a.S + qq] = s;
-  }
-}
-
 // --------------------------------------------------------------------------- dQ
 template <int DP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
@@ -279,14 +258,22 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
   const int qc = q < S ? q : S - 1;
 
   bf8_t qf[T::NK], dof[T::NK];
+  // delta = rowsum(dO * O): each query row is split over the two half-lanes, so the row sum
+  // is one cross-half exchange; it is also published for the dK/dV kernel that runs next.
+  const bf16_t *ob = a.o_in + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
+  float dsum = 0.f;
 #pragma unroll
   for (int kk = 0; kk < T::NK; ++kk) {
     qf[kk] = global_frag(qb, a.ld, qc, true, kk, half, hd);
     dof[kk] = global_frag(dob, a.ld_o, qc, true, kk, half, hd);
+    const bf8_t of = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
+  const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
   const float nlse = -a.lse_in[stat] * LOG2E;
-  const float dlt = a.delta[stat];
+  if (half == 0 && q < S) a.delta[stat] = dlt;
 
   f16_t dq[T::ND];
 #pragma unroll
@@ -473,10 +460,6 @@ int flash_fwd_launch(const FArgs &a, hipStream_t s) {
 
 template <int DP>
 int flash_bwd_launch(const FArgs &a, hipStream_t s) {
-  int64_t nb = ceil_div((int64_t)a.B * a.S * a.H, 256);
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)nb), dim3(256), 0, s, a);
-  LDM_CHECK_LAUNCH();
   dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
   hipLaunchKernelGGL(flash_bwd_dq_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
   LDM_CHECK_LAUNCH();

@@ -164,13 +164,25 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T *x, const float *w,
 }
 
 // out[c] = sum_p partial[p][c]   (deterministic second stage)
+// Block = 32 columns x 8 partial lanes; each lane strides over the partials, LDS joins them.
 __global__ __launch_bounds__(256) void reduce_partials_k(const float *partial, int64_t nparts, int64_t d,
                                                          float *out) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+  __shared__ float sm[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 32 + tx;
   float s = 0.f;
-  for (int64_t p = 0; p < nparts; ++p) s += partial[p * d + c];
-  out[c] = s;
+  if (c < d) {
+#pragma unroll 8
+    for (int64_t p = ty; p < nparts; p += 8) s += partial[p * d + c];
+  }
+  sm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < d) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sm[i][tx];
+    out[c] = t;
+  }
 }
 
 // ------------------------------------------------------------------ RoPE on fused qkv
@@ -289,21 +301,39 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const T *ag, const T *dh, in
 }
 
 // ------------------------------------------------------------------ column sums
-// Block (64 x 4): thread x owns one column, 4 row lanes; grid.y slices the rows.
+// Block (32 x 8): thread x owns 4 adjacent columns (one 4-element vector), 8 row lanes;
+// grid.y slices the rows.  Rows are read in full 128-element (bf16: 256 B) runs.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T *X, int64_t M, int64_t N, int64_t ld,
                                                 int64_t rows_per_slice, float *partial) {
-  __shared__ float sm[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  __shared__ float sm[8][32][5];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t c = ((int64_t)blockIdx.x * 32 + tx) * 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
   const int64_t r1 = (r0 + rows_per_slice < M) ? r0 + rows_per_slice : M;
-  float s = 0.f;
-  if (c < N)
-    for (int64_t r = r0 + ty; r < r1; r += 4) s += Elt<T>::ld(X + r * ld + c);
-  sm[ty][tx] = s;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (c + 3 < N && vec_ok) {
+#pragma unroll 4
+    for (int64_t r = r0 + ty; r < r1; r += 8) {
+      const f4 v = ld4(X + r * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += v.v[j];
+    }
+  } else if (c < N) {
+    for (int64_t r = r0 + ty; r < r1; r += 8)
+      for (int j = 0; j < 4 && c + j < N; ++j) s[j] += Elt<T>::ld(X + r * ld + c + j);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[ty][tx][j] = s[j];
   __syncthreads();
-  if (ty == 0 && c < N) partial[(int64_t)blockIdx.y * N + c] = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+  if (ty < 4) {
+    const int j = ty;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sm[i][tx][j];
+    if (c + j < N) partial[(int64_t)blockIdx.y * N + c + j] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_k(const float *src, bf16_t *dst, int64_t n4,
@@ -432,7 +462,7 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
   }
 #undef RMS_B
   LDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, s, dw_partial,
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(256), 0, s, dw_partial,
                      (int64_t)grid, d, dw);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
@@ -524,8 +554,8 @@ extern "C" int ldm_swiglu_bwd(const void *ag, const void *dh, int64_t T, int64_t
 }
 
 static inline int64_t colsum_slices(int64_t M) {
-  int64_t sl = ceil_div(M, 512);
-  if (sl > 256) sl = 256;
+  int64_t sl = ceil_div(M, 256);
+  if (sl > 64) sl = 64;
   if (sl < 1) sl = 1;
   return sl;
 }
@@ -540,7 +570,7 @@ extern "C" int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_
   if (!X || !ws) return LDM_E_BADARG;
   const int64_t slices = colsum_slices(M);
   const int64_t rps = ceil_div(M, slices);
-  dim3 grid((unsigned)ceil_div(N, 64), (unsigned)slices);
+  dim3 grid((unsigned)ceil_div(N, 128), (unsigned)slices);
   if (dtype == LDM_F32)
     hipLaunchKernelGGL(colsum_k<float>, grid, dim3(256), 0, s, (const float *)X, M, N, ld, rps, ws);
   else if (dtype == LDM_BF16)
@@ -548,7 +578,7 @@ extern "C" int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_
   else
     return LDM_E_DTYPE;
   LDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, ws, slices, N, out);
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, s, ws, slices, N, out);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }

@@ -22,6 +22,21 @@ extern "C" int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int
                           bias, R, ldr, 1, 1, s);
 }
 
+extern "C" int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                            const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                            void *stream) {
+  if (M < 0 || N < 0 || K < 0) return LDM_E_BADARG;
+  if (M == 0 || N == 0 || K == 0) return LDM_OK;
+  if (!A || !B || !C) return LDM_E_BADARG;
+  if (in_dtype != LDM_F32 && in_dtype != LDM_BF16) return LDM_E_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == LDM_BF16) {
+    const int rc = ldm_gemm_mfma_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+    if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
+  }
+  return ldm_gemm_generic_acc(in_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+}
+
 extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N,
                                 int64_t K, float alpha, const void *A, int64_t lda, ldm_bstride sa,
                                 const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,

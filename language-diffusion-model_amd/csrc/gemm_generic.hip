@@ -20,6 +20,7 @@ struct GArgs {
   const void *R; int64_t ldr;
   ldm_bstride sa, sb, sc;
   int64_t batch_inner;
+  int accumulate;   // C += result (C is read as TO)
 };
 
 // A_KFAST: A is contiguous along k (a_cs == 1); else contiguous along m.
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void gemm_generic_k(GArgs g) {
       float v = acc[i][j] * g.alpha;
       if (g.bias) v += g.bias[gn];
       if (g.R) v += Elt<TO>::ld((const TO *)g.R + gm * g.ldr + gn);
+      if (g.accumulate) v += Elt<TO>::ld(C + gm * g.ldc + gn);
       Elt<TO>::st(C + gm * g.ldc + gn, v);
     }
   }
@@ -110,9 +112,24 @@ int ldm_gemm_generic(int in_dtype, int out_dtype, int transA, int transB, int64_
   g.B = B; g.b_rs = transB ? 1 : ldb; g.b_cs = transB ? ldb : 1;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.sa = sa; g.sb = sb; g.sc = sc; g.batch_inner = batch_inner > 0 ? batch_inner : 1;
+  g.accumulate = 0;
   if (in_dtype == LDM_F32 && out_dtype == LDM_F32) return launch_generic<float, float>(g, transA, transB, batch, s);
   if (in_dtype == LDM_BF16 && out_dtype == LDM_BF16) return launch_generic<bf16_t, bf16_t>(g, transA, transB, batch, s);
   if (in_dtype == LDM_BF16 && out_dtype == LDM_F32) return launch_generic<bf16_t, float>(g, transA, transB, batch, s);
   if (in_dtype == LDM_F32 && out_dtype == LDM_BF16) return launch_generic<float, bf16_t>(g, transA, transB, batch, s);
+  return LDM_E_DTYPE;
+}
+
+int ldm_gemm_generic_acc(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                         const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                         hipStream_t s) {
+  GArgs g;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha;
+  g.A = A; g.a_rs = transA ? 1 : lda; g.a_cs = transA ? lda : 1;
+  g.B = B; g.b_rs = transB ? 1 : ldb; g.b_cs = transB ? ldb : 1;
+  g.C = C; g.ldc = ldc; g.bias = nullptr; g.R = nullptr; g.ldr = 0;
+  g.sa = g.sb = g.sc = ldm_bstride{0, 0}; g.batch_inner = 1; g.accumulate = 1;
+  if (in_dtype == LDM_F32) return launch_generic<float, float>(g, transA, transB, 1, s);
+  if (in_dtype == LDM_BF16) return launch_generic<bf16_t, float>(g, transA, transB, 1, s);
   return LDM_E_DTYPE;
 }

@@ -45,7 +45,7 @@ struct MArgs {
   void *C; int64_t ldc;
   const float *bias;
   const void *R; int64_t ldr;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, splits;
 };
 
 __device__ __forceinline__ int swz_tr(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
@@ -104,7 +104,9 @@ __device__ __forceinline__ bf8_t read_frag(const char *tile, int rbase, int ks, 
   }
 }
 
-template <bool A_KC, bool B_KC, typename TO>
+// EPI 0: C = alpha*acc (+bias) (+R), stored as TO.   EPI 1 (split-K): C(fp32) += alpha*acc by
+// float atomics, blocks with the same tile and different `split` each take a K range.
+template <bool A_KC, bool B_KC, typename TO, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A tile | B tile]
   const int lane = threadIdx.x & 63;
@@ -112,13 +114,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware remap (blocks b and b+8 share an XCD's L2): give each of the 8 groups
-  // a contiguous run of tiles, then walk tiles in bands of 8 m-tiles.
+  // a contiguous run of work items, then walk tiles in bands of 8 m-tiles.
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int split = bid / ntiles;
+  bid -= split * ntiles;
   int tm, tn;
   {
     const int GM = 8;
@@ -132,6 +137,12 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
+  // K range of this split, in 64-deep tiles
+  const int nt_total = (int)(g.K / BK);
+  const int base = nt_total / g.splits, rem = nt_total % g.splits;
+  const int t_begin = split * base + (split < rem ? split : rem);
+  const int nt = base + (split < rem ? 1 : 0);
+
   const bf16_t *srcA[4], *srcB[4];
   stage_ptrs<A_KC>(g.A, g.lda, m0, g.M, wave, lane, srcA);
   stage_ptrs<B_KC>(g.B, g.ldb, n0, g.N, wave, lane, srcB);
@@ -144,9 +155,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = (int)(g.K / BK);
-  stage_issue<A_KC>(srcA, 0, smem, wave);
-  stage_issue<B_KC>(srcB, 0, smem + TILE_BYTES, wave);
+  if (nt > 0) {
+    stage_issue<A_KC>(srcA, (int64_t)t_begin * kstepA, smem, wave);
+    stage_issue<B_KC>(srcB, (int64_t)t_begin * kstepB, smem + TILE_BYTES, wave);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
   __syncthreads();
 
@@ -154,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
     const char *cur = smem + (t & 1) * 2 * TILE_BYTES;
     if (t + 1 < nt) {
       char *nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-      stage_issue<A_KC>(srcA, (int64_t)(t + 1) * kstepA, nxt, wave);
-      stage_issue<B_KC>(srcB, (int64_t)(t + 1) * kstepB, nxt + TILE_BYTES, wave);
+      stage_issue<A_KC>(srcA, (int64_t)(t_begin + t + 1) * kstepA, nxt, wave);
+      stage_issue<B_KC>(srcB, (int64_t)(t_begin + t + 1) * kstepB, nxt + TILE_BYTES, wave);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -175,27 +187,50 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
     __syncthreads();
   }
 
-  // epilogue: lane holds, per fragment, row m = .. + (lane & 15), cols n = .. + (lane >> 4) * 4 + 0..3
-  TO *C = (TO *)g.C;
-  const TO *R = (const TO *)g.R;
-  const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
+  // Epilogue through LDS.  Each wave re-shapes its own 64x64 fp32 sub-tile in a private
+  // 16 KiB region (the staging buffers are free now): fragments go in as 16-byte pieces
+  // (lane: row m = mi*16 + (lane&15), 4 columns at ni*16 + (lane>>4)*4), rows come out
+  // contiguous.  16-byte column c4 of row r lives at slot c4 ^ (r & 15): conflict free both ways.
+  float *cs = reinterpret_cast<float *>(smem + wave * 16384);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int64_t m = m0 + wm * 64 + mi * 16 + (lane & 15);
-    if (m >= g.M) continue;
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int64_t n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-      if (n >= g.N) continue;
-      f4 v;
+      const int row = mi * 16 + (lane & 15);
+      const int c4 = ni * 4 + (lane >> 4);
+      float4 v = make_float4(acc[ni][mi][0] * g.alpha, acc[ni][mi][1] * g.alpha, acc[ni][mi][2] * g.alpha,
+                             acc[ni][mi][3] * g.alpha);
+      *reinterpret_cast<float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2)) = v;
+    }
+  const int64_t mw = m0 + wm * 64, nw = n0 + wn * 64;
+  if (EPI == 1) {
+    float *C = (float *)g.C;
+    const int64_t n = nw + lane;
+#pragma unroll 4
+    for (int row = 0; row < 64; ++row) {
+      const float v = cs[row * 64 + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
+      if (mw + row < g.M && n < g.N) atomicAdd(C + (mw + row) * g.ldc + n, v);   // 256 contiguous bytes per wave
+    }
+  } else {
+    TO *C = (TO *)g.C;
+    const TO *R = (const TO *)g.R;
+    const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
+    const int c4 = lane & 15;
+    const int64_t n = nw + c4 * 4;
+    f4 bv{{0.f, 0.f, 0.f, 0.f}};
+    if (g.bias) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v.v[j] = acc[ni][mi][j] * g.alpha;
+      for (int j = 0; j < 4; ++j)
+        if (n + j < g.N) bv.v[j] = g.bias[n + j];
+    }
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2));
+      const int64_t m = mw + row;
+      if (m >= g.M || n >= g.N) continue;
+      f4 v{{t.x + bv.v[0], t.y + bv.v[1], t.z + bv.v[2], t.w + bv.v[3]}};
       if (n + 3 < g.N && vec_ok) {
-        if (g.bias) {
-          const f4 b = ld4(g.bias + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v.v[j] += b.v[j];
-        }
         if (R) {
           const f4 r = ld4(R + m * g.ldr + n);
 #pragma unroll
@@ -204,38 +239,35 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
         st4(C + m * g.ldc + n, v);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
           if (n + j < g.N) {
             float x = v.v[j];
-            if (g.bias) x += g.bias[n + j];
             if (R) x += Elt<TO>::ld(R + m * g.ldr + n + j);
             Elt<TO>::st(C + m * g.ldc + n + j, x);
           }
-        }
       }
     }
   }
 }
 
-template <bool A_KC, bool B_KC, typename TO>
+template <bool A_KC, bool B_KC, typename TO, int EPI>
 int launch_mfma(const MArgs &g, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = 4 * TILE_BYTES;
   if (!attr_set) {
-    hipFuncSetAttribute((const void *)gemm_mfma_k<A_KC, B_KC, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)gemm_mfma_k<A_KC, B_KC, TO, EPI>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
-  hipLaunchKernelGGL((gemm_mfma_k<A_KC, B_KC, TO>), dim3((unsigned)nwg), dim3(256), lds, s, g);
+  const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+  hipLaunchKernelGGL((gemm_mfma_k<A_KC, B_KC, TO, EPI>), dim3((unsigned)nwg), dim3(256), lds, s, g);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }
 
-}  // namespace
-
-int ldm_gemm_mfma_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
-                       const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
-                       const float *bias, const void *R, int64_t ldr, hipStream_t s) {
+int check_and_fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+                   int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, const float *bias,
+                   const void *R, int64_t ldr) {
   if (K % BK || K <= 0) return LDM_E_SHAPE;
   if (lda % 8 || ldb % 8) return LDM_E_ALIGN;
   if (!aligned_to(A, 16) || !aligned_to(B, 16) || !aligned_to(C, 16)) return LDM_E_ALIGN;
@@ -244,19 +276,50 @@ int ldm_gemm_mfma_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t
   if (transA && (M < 8 || M % 8)) return LDM_E_SHAPE;
   if (!transB && (N < 8 || N % 8)) return LDM_E_SHAPE;
   const int64_t tm = ceil_div(M, BM), tn = ceil_div(N, BN);
-  if (tm * tn > 0x7fffffff || tm > 0x3fffffff || tn > 0x3fffffff) return LDM_E_SHAPE;
-  MArgs g;
+  if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha;
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
-  g.tiles_m = (int)tm; g.tiles_n = (int)tn;
+  g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = 1;
+  return LDM_OK;
+}
+
+}  // namespace
+
+int ldm_gemm_mfma_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                       const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
+                       const float *bias, const void *R, int64_t ldr, hipStream_t s) {
+  MArgs g;
+  const int rc = check_and_fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, R, ldr);
+  if (rc) return rc;
   const bool akc = !transA, bkc = transB != 0;
 #define GO(AK, BKC)                                                                   \
-  return out_dtype == LDM_BF16 ? launch_mfma<AK, BKC, bf16_t>(g, s)                   \
-         : out_dtype == LDM_F32 ? launch_mfma<AK, BKC, float>(g, s) : (int)LDM_E_DTYPE
+  return out_dtype == LDM_BF16 ? launch_mfma<AK, BKC, bf16_t, 0>(g, s)                \
+         : out_dtype == LDM_F32 ? launch_mfma<AK, BKC, float, 0>(g, s) : (int)LDM_E_DTYPE
   if (akc && bkc) { GO(true, true); }
   if (akc && !bkc) { GO(true, false); }
   if (!akc && bkc) { GO(false, true); }
   GO(false, false);
 #undef GO
+}
+
+// C(fp32) += alpha * opA(A) * opB(B), K split over workgroups so that small outputs with a
+// long reduction (weight gradients: K = number of tokens) still fill the chip.
+int ldm_gemm_mfma_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+                           int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s) {
+  MArgs g;
+  const int rc = check_and_fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
+  if (rc) return rc;
+  const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
+  const int64_t nt_total = K / BK;
+  int64_t splits = ceil_div(1024, ntiles);          // aim at ~4 workgroups per CU
+  if (splits > nt_total / 4) splits = nt_total / 4; // keep >= 4 K tiles per workgroup
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  g.splits = (int)splits;
+  const bool akc = !transA, bkc = transB != 0;
+  if (akc && bkc) return launch_mfma<true, true, float, 1>(g, s);
+  if (akc && !bkc) return launch_mfma<true, false, float, 1>(g, s);
+  if (!akc && bkc) return launch_mfma<false, true, float, 1>(g, s);
+  return launch_mfma<false, false, float, 1>(g, s);
 }

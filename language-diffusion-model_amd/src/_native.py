@@ -40,6 +40,7 @@ SIGNATURES = {
     "ldm_swiglu_bwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "ldm_gemm": (_i32, [_i32, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64,
                         _vp, _vp, _i64, _vp]),
+    "ldm_gemm_acc": (_i32, [_i32, _i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ldm_gemm_batched": (_i32, [_i32, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, BStride, _vp, _i64,
                                 BStride, _vp, _i64, BStride, _i64, _i64, _vp]),
     "ldm_colsum_ws_floats": (_i64, [_i64, _i64]),

@@ -138,8 +138,9 @@ class _PackedLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, k, dtype=dt, device=g.device)
             _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag=pack.name + ".dx")
-        dw = torch.empty(n_pad, k, dtype=torch.float32, device=g.device)
-        _gemm(dt, torch.float32, 1, 0, n_pad, k, T, g, n_pad, x2, x2.stride(0), dw, k, tag=pack.name + ".dw")
+        dw = torch.zeros(n_pad, k, dtype=torch.float32, device=g.device)
+        N.check(N.lib().ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad,
+                                     x2.data_ptr(), x2.stride(0), dw.data_ptr(), k, N.stream()), "ldm_gemm_acc")
         db = torch.empty(n_pad, dtype=torch.float32, device=g.device)
         ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
         N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
