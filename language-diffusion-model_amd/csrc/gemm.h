@@ -19,3 +19,10 @@ int ldm_gemm_mfma_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t
 int ldm_gemm_generic_acc(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                          const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
                          hipStream_t s);
+
+// 256-row-tile kernels (gemm_mfma256.hip); same contracts as the 128-tile forms above
+int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                          const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
+                          const float *bias, const void *R, int64_t ldr, hipStream_t s);
+int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+                              int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s);

@@ -2,6 +2,17 @@
 // else (F32 parity mode, odd shapes, batched attention products) on the FMA kernel.
 #include "common.h"
 #include "gemm.h"
+#include <stdlib.h>
+
+// LDM_GEMM_TILE=128 pins the 128x128 kernel (A/B measurements); default: 256-row tiles first.
+static int gemm_kernel_choice() {
+  static int choice = -1;
+  if (choice < 0) {
+    const char *e = getenv("LDM_GEMM_TILE");
+    choice = (e && atoi(e) == 128) ? 128 : 256;
+  }
+  return choice;
+}
 
 extern "C" int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
                         float alpha, const void *A, int64_t lda, const void *B, int64_t ldb, void *C,
@@ -13,8 +24,11 @@ extern "C" int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int
   if (out_dtype != LDM_F32 && out_dtype != LDM_BF16) return LDM_E_DTYPE;
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == LDM_BF16) {
-    const int rc = ldm_gemm_mfma_bf16(out_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias,
-                                      R, ldr, s);
+    int rc = LDM_E_SHAPE;
+    if (gemm_kernel_choice() != 128)
+      rc = ldm_gemm_mfma256_bf16(out_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, R, ldr, s);
+    if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
+    rc = ldm_gemm_mfma_bf16(out_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, R, ldr, s);
     if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
   }
   const ldm_bstride z{0, 0};
@@ -31,7 +45,11 @@ extern "C" int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int
   if (in_dtype != LDM_F32 && in_dtype != LDM_BF16) return LDM_E_DTYPE;
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == LDM_BF16) {
-    const int rc = ldm_gemm_mfma_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+    int rc = LDM_E_SHAPE;
+    if (gemm_kernel_choice() != 128)
+      rc = ldm_gemm_mfma256_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+    if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
+    rc = ldm_gemm_mfma_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
     if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
   }
   return ldm_gemm_generic_acc(in_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);

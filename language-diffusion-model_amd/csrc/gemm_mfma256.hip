@@ -1,0 +1,376 @@
+// Large-tile bf16 MFMA GEMM for gfx950: 256 x BN output tile (BN = 256 or 128), 8 waves,
+// one workgroup per CU, operands streamed global -> LDS by 16-byte LDS-DMA through a ring
+// of FOUR 32-deep half-tiles so that up to three half-tiles stay in flight across the
+// per-phase barrier (counted vmcnt, raw s_barrier).
+//
+// Why the big tile: at 128x128 a workgroup streams 32 KiB from L2 per 2.1 MFLOP
+// (64 FLOP/B); the measured L2 -> CU rate (~70 GB/s per CU) then caps the chip near
+// 1.1 PFLOP/s.  256x256 doubles the intensity.
+//
+// One phase (= one 32-deep half-tile, 32 MFMAs per wave at 256x256), per wave:
+//   segment R:  s_waitcnt vmcnt(P)      this wave's pieces of half-tile p+1 have landed
+//               ds_read fragments of half-tile p
+//               issue LDS-DMA for half-tile p+3 into the slot of p-1
+//               s_waitcnt lgkmcnt(0); s_barrier
+//   segment M:  MFMAs on the fragments; s_barrier
+// P = LDS-DMA instructions per wave per half-tile.  Waves 4-7 run one barrier behind waves
+// 0-3, so on every SIMD one wave's segment M overlaps the other's segment R.  A half-tile is
+// read only after EVERY wave's vmcnt for it and a barrier all waves passed; a slot is refilled
+// only after every wave's reads of it completed (lgkmcnt(0)) and a barrier.
+//
+// LDS images (per operand, 32 k per half-tile):
+//   K-contiguous operand (A stored [M][K] / B stored [N][K]): [rows][32 k], 64-B rows;
+//     16-B chunk c of row r sits at chunk c ^ (3 * ((r >> 2) & 1))   (ds_read_b128 conflict free)
+//   strided operand (A stored [K][M] / B stored [K][N]): [32 k][cols], 256/512-B rows;
+//     16-B chunk c of row k sits at c ^ (s(k) << 1), s(k) = (k & 3) | (((k >> 3) & 1) << 2)
+//     (ds_read_b64_tr_b16 conflict free)
+// The swizzle is applied to the per-lane SOURCE address of the LDS-DMA (its LDS
+// destination is lane-linear) and again on the read.
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+
+constexpr int BM = 256;
+constexpr int KH = 32;                 // k depth of a half-tile
+constexpr int LDS_BYTES = 128 * 1024;  // ring (<= 128 KiB) and the epilogue staging (8 x 16 KiB)
+
+struct MArgs {
+  int64_t M, N, K;
+  float alpha;
+  const bf16_t *A; int64_t lda;
+  const bf16_t *B; int64_t ldb;
+  void *C; int64_t ldc;
+  const float *bias;
+  const void *R; int64_t ldr;
+  int tiles_m, tiles_n, splits;
+};
+
+__device__ __forceinline__ int swz_kc(int row) { return 3 * ((row >> 2) & 1); }
+__device__ __forceinline__ int swz_st(int kr) { return ((kr & 3) | (((kr >> 3) & 1) << 2)) << 1; }
+
+// Source pointers of the LDS-DMA pieces (1 KiB each) this wave issues per half-tile of an
+// operand with ROWS rows (KC) or ROWS columns (strided).  Piece index = wave + 8*i.
+template <bool KC, int ROWS>
+__device__ __forceinline__ void stage_ptrs(const bf16_t *P, int64_t ld, int64_t row0, int64_t nrows, int wave,
+                                           int lane, const bf16_t *(&src)[ROWS / 128]) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 128; ++i) {
+    const int piece = wave + 8 * i;
+    if (KC) {
+      const int r = piece * 16 + (lane >> 2);
+      const int lc = (lane & 3) ^ swz_kc(r);
+      int64_t gr = row0 + r;
+      if (gr > nrows - 1) gr = nrows - 1;
+      src[i] = P + gr * ld + lc * 8;
+    } else {
+      constexpr int RB = ROWS * 2;              // bytes per k row of the image
+      constexpr int RPP = 1024 / RB;            // k rows per piece
+      const int kr = piece * RPP + (lane * 16) / RB;
+      const int pc = ((lane * 16) % RB) / 16;
+      const int lc = pc ^ swz_st(kr);
+      int64_t col = row0 + lc * 8;
+      if (col > nrows - 8) col = nrows - 8;
+      src[i] = P + (int64_t)kr * ld + col;
+    }
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ void stage_issue(const bf16_t *(&src)[NP], int64_t koff, char *img, int wave) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + koff), LDS_PTR(img + (wave + 8 * i) * 1024), 16, 0, 0);
+}
+
+// 16 (rows or cols) x 32 k fragment of a half-tile image
+template <bool KC, int ROWS>
+__device__ __forceinline__ bf8_t read_frag(const char *img, int rbase, int lane) {
+  if (KC) {
+    const int r = rbase + (lane & 15);
+    const int pc = (lane >> 4) ^ swz_kc(r);
+    return *reinterpret_cast<const bf8_t *>(img + r * 64 + pc * 16);
+  } else {
+    constexpr int RB = ROWS * 2;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int kr0 = 8 * g + q;
+    const int ch = ((rbase >> 3) + (p >> 1)) ^ swz_st(kr0);       // swz_st(kr0 + 4) == swz_st(kr0)
+    const char *a0 = img + kr0 * RB + (ch << 4) + ((p & 1) << 3);
+    s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0));
+    s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0 + 4 * RB));
+    s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf8_t, v);
+  }
+}
+
+// BN: 256 (waves 2M x 4N, 128x64 per wave) or 128 (waves 4M x 2N, 64x64 per wave)
+template <bool A_KC, bool B_KC, int BN, typename TO, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
+  constexpr int WN_ = BN / 64;            // waves along N
+  constexpr int WM_ = 8 / WN_;            // waves along M
+  constexpr int MI = BM / WM_ / 16;       // 16-row fragments per wave
+  constexpr int NI = 4;                   // 16-col fragments per wave (64 columns)
+  constexpr int PA = BM / 128, PB = BN / 128;   // LDS-DMA pieces per wave per half-tile
+  constexpr int HT_A = BM * 64, HT_B = BN * 64; // bytes of one half-tile image
+  constexpr int HT = HT_A + HT_B;
+  constexpr int P = PA + PB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN_, wn = wave % WN_;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int split = bid / ntiles;
+  bid -= split * ntiles;
+  int tm, tn;
+  {
+    const int GM = 4;
+    const int width = GM * g.tiles_n;
+    const int grp = bid / width;
+    const int first = grp * GM;
+    const int gsz = (g.tiles_m - first < GM) ? g.tiles_m - first : GM;
+    const int in = bid - grp * width;
+    tm = first + in % gsz;
+    tn = in / gsz;
+  }
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int np_total = (int)(g.K / KH);
+  const int base = np_total / g.splits, rem = np_total % g.splits;
+  const int p_begin = split * base + (split < rem ? split : rem);
+  const int np = base + (split < rem ? 1 : 0);
+
+  const bf16_t *srcA[PA], *srcB[PB];
+  stage_ptrs<A_KC, BM>(g.A, g.lda, m0, g.M, wave, lane, srcA);
+  stage_ptrs<B_KC, BN>(g.B, g.ldb, n0, g.N, wave, lane, srcB);
+  const int64_t kstepA = A_KC ? KH : (int64_t)KH * g.lda;
+  const int64_t kstepB = B_KC ? KH : (int64_t)KH * g.ldb;
+
+  f4_t acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: half-tiles 0, 1, 2 in flight; half-tile 0 landed for everybody
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    if (p < np) {
+      stage_issue<PA>(srcA, (int64_t)(p_begin + p) * kstepA, smem + p * HT, wave);
+      stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
+    }
+  if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+  else if (np > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // The two halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run ONE
+  // barrier apart: while one half is in its MFMA segment the other reads LDS and issues
+  // LDS-DMA.  The second half takes one extra barrier here and the first half one after
+  // the loop, so every s_barrier below pairs segment R of one half with segment M of the other.
+  const bool late = wave >= 4;
+  if (late) __builtin_amdgcn_s_barrier();
+
+  for (int p = 0; p < np; ++p) {
+    // ---- segment R: retire this wave's pieces of half-tile p+1, read p, refill the slot of p-1
+    if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char *cur = smem + (p & 3) * HT;
+    bf8_t fa[MI], fb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fb[i] = read_frag<B_KC, BN>(cur + HT_A, wn * 64 + i * 16, lane);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_KC, BM>(cur, wm * (MI * 16) + i * 16, lane);
+    if (p + 3 < np) {
+      char *slot = smem + ((p + 3) & 3) * HT;
+      stage_issue<PA>(srcA, (int64_t)(p_begin + p + 3) * kstepA, slot, wave);
+      stage_issue<PB>(srcB, (int64_t)(p_begin + p + 3) * kstepB, slot + HT_A, wave);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of half-tile p are complete
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- segment M
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave is done with the ring: it becomes the epilogue staging area
+
+  // Epilogue through LDS, 64 rows x 64 columns of fp32 (16 KiB) per wave at a time:
+  // fragments go in as 16-byte pieces at chunk c4 ^ (row & 15), rows come out contiguous.
+  float *cs = reinterpret_cast<float *>(smem + wave * 16384);
+  const int64_t nw = n0 + wn * 64;
+#pragma unroll
+  for (int half = 0; half < MI / 4; ++half) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = mi * 16 + (lane & 15);
+        const int c4 = ni * 4 + (lane >> 4);
+        const f4_t a = acc[ni][half * 4 + mi];
+        *reinterpret_cast<float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2)) =
+            make_float4(a[0] * g.alpha, a[1] * g.alpha, a[2] * g.alpha, a[3] * g.alpha);
+      }
+    const int64_t mw = m0 + wm * (MI * 16) + half * 64;
+    if (EPI == 1) {
+      float *C = (float *)g.C;
+      const int64_t n = nw + lane;
+#pragma unroll 4
+      for (int row = 0; row < 64; ++row) {
+        const float v = cs[row * 64 + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
+        if (mw + row < g.M && n < g.N) atomicAdd(C + (mw + row) * g.ldc + n, v);   // 256 contiguous bytes
+      }
+    } else {
+      TO *C = (TO *)g.C;
+      const TO *R = (const TO *)g.R;
+      const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
+      const int c4 = lane & 15;
+      const int64_t n = nw + c4 * 4;
+      f4 bv{{0.f, 0.f, 0.f, 0.f}};
+      if (g.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < g.N) bv.v[j] = g.bias[n + j];
+      }
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2));
+        const int64_t m = mw + row;
+        if (m >= g.M || n >= g.N) continue;
+        f4 v{{t.x + bv.v[0], t.y + bv.v[1], t.z + bv.v[2], t.w + bv.v[3]}};
+        if (n + 3 < g.N && vec_ok) {
+          if (R) {
+            const f4 r = ld4(R + m * g.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.v[j] += r.v[j];
+          }
+          st4(C + m * g.ldc + n, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j < g.N) {
+              float x = v.v[j];
+              if (R) x += Elt<TO>::ld(R + m * g.ldr + n + j);
+              Elt<TO>::st(C + m * g.ldc + n + j, x);
+            }
+        }
+      }
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, int BN, typename TO, int EPI>
+int launch256(const MArgs &g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)gemm256_k<A_KC, B_KC, BN, TO, EPI>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+  hipLaunchKernelGGL((gemm256_k<A_KC, B_KC, BN, TO, EPI>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, s, g);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <int BN, typename TO, int EPI>
+int dispatch_layout(const MArgs &g, bool akc, bool bkc, hipStream_t s) {
+  if (akc && bkc) return launch256<true, true, BN, TO, EPI>(g, s);
+  if (akc && !bkc) return launch256<true, false, BN, TO, EPI>(g, s);
+  if (!akc && bkc) return launch256<false, true, BN, TO, EPI>(g, s);
+  return launch256<false, false, BN, TO, EPI>(g, s);
+}
+
+int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+         int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, const float *bias, const void *R,
+         int64_t ldr) {
+  if (K % KH || K <= 0) return LDM_E_SHAPE;
+  if (lda % 8 || ldb % 8) return LDM_E_ALIGN;
+  if (!aligned_to(A, 16) || !aligned_to(B, 16) || !aligned_to(C, 16)) return LDM_E_ALIGN;
+  if (bias && !aligned_to(bias, 16)) return LDM_E_ALIGN;
+  if (R && !aligned_to(R, 16)) return LDM_E_ALIGN;
+  if (transA && (M < 8 || M % 8)) return LDM_E_SHAPE;
+  if (!transB && (N < 8 || N % 8)) return LDM_E_SHAPE;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha;
+  g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
+  g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
+  g.splits = 1;
+  return LDM_OK;
+}
+
+// wave-quantisation efficiency of `tiles` workgroups on 256 CUs
+double quant_eff(int64_t tiles) { return (double)tiles / (double)(ceil_div(tiles, 256) * 256); }
+
+}  // namespace
+
+// Picks the N tile: 256 unless 128 fills the 256 CUs distinctly better.  Returns
+// LDM_E_SHAPE for problems too small to be worth a 256-row tile (caller falls back).
+int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                          const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
+                          const float *bias, const void *R, int64_t ldr, hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, R, ldr);
+  if (rc) return rc;
+  if (M < 256 || N < 128) return LDM_E_SHAPE;
+  const int64_t tm = ceil_div(M, BM);
+  const int64_t t256 = tm * ceil_div(N, 256), t128 = tm * ceil_div(N, 128);
+  if (t128 > 0x3fffffff) return LDM_E_SHAPE;
+  // 256x128 tiles stream 1.5x the bytes per flop of 256x256: only when they fill the chip better
+  const bool use128 = N < 256 || quant_eff(t128) * 0.85 > quant_eff(t256) * ((double)N / (ceil_div(N, 256) * 256.0));
+  g.tiles_m = (int)tm;
+  g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
+  const bool akc = !transA, bkc = transB != 0;
+  if (out_dtype == LDM_BF16)
+    return use128 ? dispatch_layout<128, bf16_t, 0>(g, akc, bkc, s) : dispatch_layout<256, bf16_t, 0>(g, akc, bkc, s);
+  if (out_dtype == LDM_F32)
+    return use128 ? dispatch_layout<128, float, 0>(g, akc, bkc, s) : dispatch_layout<256, float, 0>(g, akc, bkc, s);
+  return LDM_E_DTYPE;
+}
+
+int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+                              int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
+  if (rc) return rc;
+  if (M < 256 || N < 128) return LDM_E_SHAPE;
+  const int64_t tm = ceil_div(M, BM);
+  const bool use128 = N < 256 || (N % 256 != 0 && N % 256 <= 128);
+  const int64_t tn = ceil_div(N, use128 ? 128 : 256);
+  const int64_t ntiles = tm * tn;
+  if (ntiles > 0x3fffffff) return LDM_E_SHAPE;
+  const int64_t np_total = K / KH;
+  int64_t splits = ntiles >= 256 ? 1 : ceil_div(512, ntiles);   // ~2 waves of workgroups over the chip
+  if (splits > np_total / 8) splits = np_total / 8;              // >= 8 half-tiles per workgroup
+  if (splits > 128) splits = 128;
+  if (splits < 1) splits = 1;
+  g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = (int)splits;
+  const bool akc = !transA, bkc = transB != 0;
+  return use128 ? dispatch_layout<128, float, 1>(g, akc, bkc, s) : dispatch_layout<256, float, 1>(g, akc, bkc, s);
+}
