@@ -102,15 +102,24 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=64)
     args = ap.parse_args()
 
+    if os.environ.get("LDM_FAULT_TIMEOUT"):     # debugging aid: dump python stacks if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LDM_FAULT_TIMEOUT"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("LDM_DP_SAME_GPU"):      # rehearsal of the multi-rank path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("LDM_DP_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from src import ops
     from src.dp import HipAccelerator

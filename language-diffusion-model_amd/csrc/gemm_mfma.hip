@@ -23,6 +23,7 @@
 // A/B 16-byte aligned, M >= 1, N >= 8 for strided B, M >= 8 for strided A.
 #include "common.h"
 #include "gemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -312,7 +313,9 @@ int ldm_gemm_mfma_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t
   if (rc) return rc;
   const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
   const int64_t nt_total = K / BK;
-  int64_t splits = ceil_div(1024, ntiles);          // aim at ~4 workgroups per CU
+  // 2 workgroups per CU are resident: take the largest split count that still fits in ONE
+  // round of 512 workgroups (equal-length workgroups: 540 of them would take two rounds).
+  int64_t splits = 512 / ntiles;
   if (splits > nt_total / 4) splits = nt_total / 4; // keep >= 4 K tiles per workgroup
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;

@@ -28,6 +28,7 @@
 // destination is lane-linear) and again on the read.
 #include "common.h"
 #include "gemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -366,9 +367,13 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
   const int64_t ntiles = tm * tn;
   if (ntiles > 0x3fffffff) return LDM_E_SHAPE;
   const int64_t np_total = K / KH;
-  int64_t splits = ntiles >= 256 ? 1 : ceil_div(512, ntiles);   // ~2 waves of workgroups over the chip
+  // Small outputs with a long reduction go to the 128x128 kernel: filling 256 CUs with
+  // 256x256 tiles would need so many K splits that the float-atomic epilogue
+  // (~1.3 TB/s chip-wide) costs more than the product itself.
+  static const bool force = getenv("LDM_GEMM_TILE") && atoi(getenv("LDM_GEMM_TILE")) == 256;
+  if (ntiles < 200 && !force) return LDM_E_SHAPE;
+  int64_t splits = ntiles >= 200 ? 1 : 256 / ntiles;
   if (splits > np_total / 8) splits = np_total / 8;              // >= 8 half-tiles per workgroup
-  if (splits > 128) splits = 128;
   if (splits < 1) splits = 1;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = (int)splits;
   const bool akc = !transA, bkc = transB != 0;

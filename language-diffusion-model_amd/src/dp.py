@@ -25,6 +25,8 @@ than DDP's 25 MiB are the better trade on one MI355X node.
 
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -44,6 +46,7 @@ class _Bucket:
         self.pending = len(params)
         self.ready = set()
         self.work = None
+        self.host = None
 
     def view_for(self, p):
         off = self.offsets[p]
@@ -56,6 +59,8 @@ class GradBucketDataParallel(nn.Module):
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # LDM_DP_FORCE=1 keeps the bucket/all-reduce machinery active on a single rank (rehearsal)
+        self._active = self.world_size > 1 or (dist.is_initialized() and os.environ.get("LDM_DP_FORCE") == "1")
         params = [p for p in module.parameters() if p.requires_grad]
         self._buckets: list[_Bucket] = []
         self._bucket_of = {}
@@ -73,10 +78,18 @@ class GradBucketDataParallel(nn.Module):
         self._next = 0
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         # identical starting point on every rank (DDP broadcasts rank 0's state too)
+        # gloo cannot be trusted with device memory here (two ranks sharing one GPU stall inside
+        # its device path): with that backend the payload is staged through host memory.
+        self._host_staged = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
         if self.world_size > 1:
+            src = dist.get_global_rank(process_group, 0) if process_group else 0
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=dist.get_global_rank(process_group, 0) if process_group else 0,
-                               group=process_group)
+                if self._host_staged and t.is_cuda:
+                    h = t.data.cpu()
+                    dist.broadcast(h, src=src, group=process_group)
+                    t.data.copy_(h)
+                else:
+                    dist.broadcast(t.data, src=src, group=process_group)
 
     def _add_bucket(self, params):
         b = _Bucket(list(params), params[0].device)
@@ -99,7 +112,7 @@ class GradBucketDataParallel(nn.Module):
         return len(self._buckets)
 
     def _on_grad(self, p):
-        if self.world_size == 1:
+        if not self._active:
             return
         if not self._callback_queued:
             Variable._execution_engine.queue_callback(self._finalize)
@@ -121,7 +134,12 @@ class GradBucketDataParallel(nn.Module):
             b = self._buckets[self._next]
             if len(b.ready) != len(b.params):
                 break
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            if self._host_staged and b.flat.is_cuda:
+                b.host = b.flat.cpu()
+                b.work = dist.all_reduce(b.host, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            else:
+                b.host = None
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             self._next += 1
 
     def _finalize(self):
@@ -139,6 +157,9 @@ class GradBucketDataParallel(nn.Module):
         inv = 1.0 / self.world_size
         for b in self._buckets:
             b.work.wait()
+            if b.host is not None:
+                b.flat.copy_(b.host)
+                b.host = None
             b.flat.mul_(inv)
             b.work = None
             b.ready.clear()
@@ -177,7 +198,7 @@ class HipAccelerator:
                 for m in o.modules():
                     if hasattr(m, "set_compute_dtype"):
                         m.set_compute_dtype(dtype)
-                if self.num_processes > 1:
+                if self.num_processes > 1 or (dist.is_initialized() and os.environ.get("LDM_DP_FORCE") == "1"):
                     o = GradBucketDataParallel(o, bucket_bytes=self.bucket_bytes)
             out.append(o)
         return out[0] if len(out) == 1 else tuple(out)
