@@ -182,6 +182,37 @@ int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, 
                int norm_mode, const float *row_lse, const float *count, const float *gout,
                void *dlogits, int64_t ld_d, void *stream);
 
+/* ---------------------------------------------------------------- LM-head backward over masked rows only
+ * The cross-entropy gradient is zero on rows that do not participate (about half of all rows
+ * for t ~ U(0,1)), so the two backward GEMMs of the vocabulary projection
+ * (src/transformer.py:441 under autograd) can skip them.  The row count is known only on the
+ * device, so these forms take it as a device pointer and never synchronise with the host.
+ *   ldm_ce_compact_rows : rows[0..count) = ascending indices of participating rows
+ *   ldm_ce_bwd_compact  : as ldm_ce_bwd but writes compact row i (= source row rows[i]) of
+ *                         dlogits [T, ld_d]; rows count..roundup(count,64) are zeroed
+ *   ldm_gather_rows     : out[i,:] = x[rows[i],:] (same zero rounding rows); out has
+ *                         roundup(max_rows,64) rows
+ *   ldm_gemm_rows_dyn   : C[row_map[m], :] = A[m, :K] * opB(B) for m < *m_dev   (BF16, MFMA)
+ *   ldm_gemm_acc_kdyn   : C(fp32) += opA(A) * opB(B) with K = roundup(*k_dev, 32) (BF16, MFMA)
+ *   ldm_colsum_rows_dyn : ldm_colsum over the first *m_dev rows
+ * The GEMM forms return LDM_E_SHAPE / LDM_E_ALIGN for problems the MFMA kernel does not take. */
+int ldm_ce_compact_rows(int64_t T, int64_t seq, const int64_t *masked_ids, int64_t mask_token_id,
+                        const uint8_t *mask_bool, const uint8_t *att_valid, int32_t *rows, int32_t *count,
+                        void *stream);
+int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, int64_t seq,
+                       const int64_t *targets, const float *seq_weight, int norm_mode, const float *row_lse,
+                       const float *count, const float *gout, const int32_t *rows, const int32_t *count_i,
+                       void *dlogits, int64_t ld_d, void *stream);
+int ldm_gather_rows(const void *x, int dtype, int64_t ld, const int32_t *rows, const int32_t *count,
+                    int64_t max_rows, int64_t d, void *out, void *stream);
+int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                      const void *B, int64_t ldb, void *C, int64_t ldc, const int32_t *m_dev,
+                      const int32_t *row_map, void *stream);
+int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                      const void *B, int64_t ldb, float *C, int64_t ldc, const int32_t *k_dev, void *stream);
+int ldm_colsum_rows_dyn(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
+                        const int32_t *m_dev, void *stream);
+
 /* ---------------------------------------------------------------- fp32 softmax helpers
  * Used by the F32 attention path (materialised scores, as the reference does at
  * src/transformer.py:264-281).  Exposed for testing. */

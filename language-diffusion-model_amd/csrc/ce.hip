@@ -184,6 +184,72 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_k(const T *logits, CeArgs a, 
   }
 }
 
+// Compaction: rows[0..count) = indices of the participating rows in ascending order.
+// One 1024-thread block; each thread owns a contiguous run of rows.
+__global__ __launch_bounds__(1024) void ce_compact_k(CeArgs a, int *rows, int *count) {
+  __shared__ int part[1024];
+  const int64_t per = (a.T + 1023) / 1024;
+  const int64_t r0 = (int64_t)threadIdx.x * per;
+  const int64_t r1 = (r0 + per < a.T) ? r0 + per : a.T;
+  int c = 0;
+  for (int64_t r = r0; r < r1; ++r) c += row_active(a, r) ? 1 : 0;
+  part[threadIdx.x] = c;
+  __syncthreads();
+  // inclusive scan (Hillis-Steele) over 1024 partial counts
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int pos = part[threadIdx.x] - c;
+  for (int64_t r = r0; r < r1; ++r)
+    if (row_active(a, r)) rows[pos++] = (int)r;
+  if (threadIdx.x == 1023) count[0] = part[1023];
+}
+
+// Backward into the COMPACT layout: block i handles compact row i (source row rows[i]);
+// rows count .. roundup(count, 64) are zero-filled so that a 32/64-deep reduction over the
+// compact rows can run past the count; later rows are not touched.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_compact_k(const T *logits, CeArgs a, const float *row_lse,
+                                                        const float *countf, const float *gout, const int *rows,
+                                                        const int *count, T *dl, int64_t ld_d) {
+  const int cnt = count[0];
+  const int64_t i = blockIdx.x;
+  if (i >= (((int64_t)cnt + 63) / 64) * 64) return;
+  T *drow = dl + i * ld_d;
+  const int64_t nv_d = ld_d >> 2;
+  if (i >= cnt) {
+    const f4 z{{0.f, 0.f, 0.f, 0.f}};
+    for (int64_t c = threadIdx.x; c < nv_d; c += 256) st4(drow + c * 4, z);
+    return;
+  }
+  const int64_t r = rows[i];
+  const T *row = logits + r * a.ld;
+  const float norm = a.norm_mode == 0 ? countf[0] : (float)a.T;
+  const float w = a.seq_weight ? a.seq_weight[r / a.seq] : 1.0f;
+  const float coef = gout[0] * w / norm;
+  const float lse = row_lse[r];
+  const int64_t tgt = a.targets[r];
+  const int64_t nv = a.V >> 2;
+  for (int64_t c = threadIdx.x; c < nv_d; c += 256) {
+    f4 o{{0.f, 0.f, 0.f, 0.f}};
+    if (c < nv) {
+      const f4 v = ld4(row + c * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.v[j] = (__expf(v.v[j] - lse) - ((c * 4 + j) == tgt ? 1.0f : 0.f)) * coef;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t cc = c * 4 + j;
+        if (cc < a.V) o.v[j] = (__expf(Elt<T>::ld(row + cc) - lse) - (cc == tgt ? 1.0f : 0.f)) * coef;
+      }
+    }
+    st4(drow + c * 4, o);
+  }
+}
+
 }  // namespace
 
 static int ce_args(CeArgs &a, int64_t ld, int64_t T, int64_t V, int64_t seq, const int64_t *targets,
@@ -254,6 +320,43 @@ extern "C" int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, 
   } else {
     return LDM_E_DTYPE;
   }
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_ce_compact_rows(int64_t T, int64_t seq, const int64_t *masked_ids, int64_t mask_token_id,
+                                   const uint8_t *mask_bool, const uint8_t *att_valid, int32_t *rows,
+                                   int32_t *count, void *stream) {
+  if (T < 0 || T > 0x7fffffff || !rows || !count || (!masked_ids && !mask_bool)) return LDM_E_BADARG;
+  CeArgs a{};
+  a.T = T; a.V = 1; a.ld = 1; a.seq = seq > 0 ? seq : 1; a.masked_ids = masked_ids; a.mask_token_id = mask_token_id;
+  a.mask_bool = mask_bool; a.att_valid = att_valid;
+  hipLaunchKernelGGL(ce_compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, rows, count);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, int64_t seq,
+                                  const int64_t *targets, const float *seq_weight, int norm_mode,
+                                  const float *row_lse, const float *count, const float *gout,
+                                  const int32_t *rows, const int32_t *count_i, void *dlogits, int64_t ld_d,
+                                  void *stream) {
+  if (T <= 0) return T == 0 ? LDM_OK : LDM_E_BADARG;
+  if (!logits || !targets || !row_lse || !count || !gout || !rows || !count_i || !dlogits || ld_d < V)
+    return LDM_E_BADARG;
+  if (T > 0x7fffffff) return LDM_E_SHAPE;
+  const size_t esz = dtype == LDM_F32 ? 4 : 2;
+  if (!aligned_to(logits, 4 * esz) || (ld % 4) || !aligned_to(dlogits, 4 * esz) || (ld_d % 4)) return LDM_E_ALIGN;
+  CeArgs a{};
+  a.ld = ld; a.T = T; a.V = V; a.seq = seq > 0 ? seq : 1; a.targets = targets; a.seq_weight = seq_weight;
+  a.norm_mode = norm_mode;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(ce_bwd_compact_k<float>, dim3((unsigned)(((T + 63) / 64) * 64)), dim3(256), 0, s, (const float *)logits, a, row_lse, count, gout, rows, count_i, (float *)dlogits, ld_d);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(ce_bwd_compact_k<bf16_t>, dim3((unsigned)(((T + 63) / 64) * 64)), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, count, gout, rows, count_i, (bf16_t *)dlogits, ld_d);
+  else
+    return LDM_E_DTYPE;
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const T *ag, const T *dh, in
 // grid.y slices the rows.  Rows are read in full 128-element (bf16: 256 B) runs.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T *X, int64_t M, int64_t N, int64_t ld,
-                                                int64_t rows_per_slice, float *partial) {
+                                                int64_t rows_per_slice, float *partial, const int *m_dev) {
+  if (m_dev) M = m_dev[0] < M ? m_dev[0] : M;   // row count known only on the device
   __shared__ float sm[8][32][5];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int64_t c = ((int64_t)blockIdx.x * 32 + tx) * 4;
@@ -334,6 +335,24 @@ __global__ __launch_bounds__(256) void colsum_k(const T *X, int64_t M, int64_t N
     for (int i = 0; i < 8; ++i) t += sm[i][tx][j];
     if (c + j < N) partial[(int64_t)blockIdx.y * N + c + j] = t;
   }
+}
+
+// out[i, :] = x[rows[i], :] for i < count; rows count .. roundup(count, 64) are zero-filled.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_k(const T *x, int64_t ld, const int *rows, const int *count,
+                                                     int64_t d, T *out) {
+  const int cnt = count[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per output row
+  if (i >= (((int64_t)cnt + 63) / 64) * 64) return;
+  T *dst = out + i * d;
+  if (i >= cnt) {
+    const f4 z{{0.f, 0.f, 0.f, 0.f}};
+    for (int64_t c = lane * 4; c < d; c += 256) st4(dst + c, z);
+    return;
+  }
+  const T *src = x + (int64_t)rows[i] * ld;
+  for (int64_t c = lane * 4; c < d; c += 256) st4(dst + c, ld4(src + c));
 }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_k(const float *src, bf16_t *dst, int64_t n4,
@@ -562,8 +581,40 @@ static inline int64_t colsum_slices(int64_t M) {
 
 extern "C" int64_t ldm_colsum_ws_floats(int64_t M, int64_t N) { return colsum_slices(M) * N; }
 
+static int colsum_impl(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
+                       const int *m_dev, void *stream);
+
 extern "C" int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
                           void *stream) {
+  return colsum_impl(X, dtype, M, N, ld, out, ws, nullptr, stream);
+}
+
+extern "C" int ldm_colsum_rows_dyn(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out,
+                                   float *ws, const int32_t *m_dev, void *stream) {
+  if (!m_dev) return LDM_E_BADARG;
+  return colsum_impl(X, dtype, M, N, ld, out, ws, m_dev, stream);
+}
+
+extern "C" int ldm_gather_rows(const void *x, int dtype, int64_t ld, const int32_t *rows, const int32_t *count,
+                               int64_t max_rows, int64_t d, void *out, void *stream) {
+  if (max_rows < 0 || d <= 0) return LDM_E_BADARG;
+  if (max_rows == 0) return LDM_OK;
+  if (!x || !rows || !count || !out) return LDM_E_BADARG;
+  if (d % 4 || ld % 4) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(out, 16)) return LDM_E_ALIGN;
+  const unsigned grid = (unsigned)ceil_div(((max_rows + 63) / 64) * 64, 4);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(gather_rows_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, ld, rows, count, d, (float *)out);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(gather_rows_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ld, rows, count, d, (bf16_t *)out);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+static int colsum_impl(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
+                       const int *m_dev, void *stream) {
   if (M < 0 || N <= 0 || !out) return LDM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) return (int)hipMemsetAsync(out, 0, N * sizeof(float), s);
@@ -572,9 +623,9 @@ extern "C" int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_
   const int64_t rps = ceil_div(M, slices);
   dim3 grid((unsigned)ceil_div(N, 128), (unsigned)slices);
   if (dtype == LDM_F32)
-    hipLaunchKernelGGL(colsum_k<float>, grid, dim3(256), 0, s, (const float *)X, M, N, ld, rps, ws);
+    hipLaunchKernelGGL(colsum_k<float>, grid, dim3(256), 0, s, (const float *)X, M, N, ld, rps, ws, m_dev);
   else if (dtype == LDM_BF16)
-    hipLaunchKernelGGL(colsum_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, M, N, ld, rps, ws);
+    hipLaunchKernelGGL(colsum_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)X, M, N, ld, rps, ws, m_dev);
   else
     return LDM_E_DTYPE;
   LDM_CHECK_LAUNCH();

@@ -55,6 +55,22 @@ extern "C" int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int
   return ldm_gemm_generic_acc(in_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
 }
 
+extern "C" int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K, const void *A,
+                                 int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
+                                 const int32_t *m_dev, const int32_t *row_map, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !m_dev) return LDM_E_BADARG;
+  return ldm_gemm_mfma256_bf16_dyn(out_dtype, 0, transB, M, N, K, 1.0f, A, lda, B, ldb, C, ldc, m_dev, row_map,
+                                   (hipStream_t)stream);
+}
+
+extern "C" int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, const void *A,
+                                 int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                                 const int32_t *k_dev, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !k_dev) return LDM_E_BADARG;
+  return ldm_gemm_mfma256_bf16_acc_dynk(transA, transB, M, N, K, 1.0f, A, lda, B, ldb, C, ldc, k_dev,
+                                        (hipStream_t)stream);
+}
+
 extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N,
                                 int64_t K, float alpha, const void *A, int64_t lda, ldm_bstride sa,
                                 const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,

@@ -53,6 +53,10 @@ struct MArgs {
   const float *bias;
   const void *R; int64_t ldr;
   int tiles_m, tiles_n, splits;
+  // optional device-side sizes (a row count known only on the GPU): rows >= *dyn_m of A/C do
+  // not exist; K is *dyn_k rounded up to 32 (the caller zero-fills the rounding rows);
+  // row_map sends output row m to C row row_map[m]
+  const int *dyn_m, *dyn_k, *row_map;
 };
 
 __device__ __forceinline__ int swz_kc(int row) { return 3 * ((row >> 2) & 1); }
@@ -150,14 +154,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     tn = in / gsz;
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t Mdyn = g.dyn_m ? (int64_t)*g.dyn_m : g.M;
+  if (m0 >= Mdyn) return;   // workgroup-uniform: nobody of this workgroup reaches a barrier
+  const int64_t Kdyn = g.dyn_k ? (((int64_t)*g.dyn_k + KH - 1) / KH) * KH : g.K;
 
-  const int np_total = (int)(g.K / KH);
+  const int np_total = (int)(Kdyn / KH);
   const int base = np_total / g.splits, rem = np_total % g.splits;
   const int p_begin = split * base + (split < rem ? split : rem);
   const int np = base + (split < rem ? 1 : 0);
 
   const bf16_t *srcA[PA], *srcB[PB];
-  stage_ptrs<A_KC, BM>(g.A, g.lda, m0, g.M, wave, lane, srcA);
+  stage_ptrs<A_KC, BM>(g.A, g.lda, m0, Mdyn, wave, lane, srcA);
   stage_ptrs<B_KC, BN>(g.B, g.ldb, n0, g.N, wave, lane, srcB);
   const int64_t kstepA = A_KC ? KH : (int64_t)KH * g.lda;
   const int64_t kstepB = B_KC ? KH : (int64_t)KH * g.ldb;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
 #pragma unroll 4
       for (int row = 0; row < 64; ++row) {
         const float v = cs[row * 64 + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
-        if (mw + row < g.M && n < g.N) atomicAdd(C + (mw + row) * g.ldc + n, v);   // 256 contiguous bytes
+        if (mw + row < Mdyn && n < g.N) atomicAdd(C + (mw + row) * g.ldc + n, v);   // 256 contiguous bytes
       }
     } else {
       TO *C = (TO *)g.C;
@@ -263,8 +270,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + (lane >> 4);
         const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2));
-        const int64_t m = mw + row;
-        if (m >= g.M || n >= g.N) continue;
+        int64_t m = mw + row;
+        if (m >= Mdyn || n >= g.N) continue;
+        if (g.row_map) m = g.row_map[m];
         f4 v{{t.x + bv.v[0], t.y + bv.v[1], t.z + bv.v[2], t.w + bv.v[3]}};
         if (n + 3 < g.N && vec_ok) {
           if (R) {
@@ -323,6 +331,7 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.splits = 1;
+  g.dyn_m = g.dyn_k = g.row_map = nullptr;
   return LDM_OK;
 }
 
@@ -353,6 +362,43 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
   if (out_dtype == LDM_F32)
     return use128 ? dispatch_layout<128, float, 0>(g, akc, bkc, s) : dispatch_layout<256, float, 0>(g, akc, bkc, s);
   return LDM_E_DTYPE;
+}
+
+// Forms with device-side sizes (see MArgs): used for the LM-head backward over the compacted
+// masked rows.  dyn_m/row_map apply to the store form, dyn_k to the accumulate form.
+int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                              const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
+                              const int *dyn_m, const int *row_map, hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
+  if (rc) return rc;
+  if (transA || M < 256 || N < 128) return LDM_E_SHAPE;
+  g.dyn_m = dyn_m; g.row_map = row_map;
+  const bool use128 = N < 256 || (N % 256 != 0 && N % 256 <= 128) || ceil_div(M, BM) * ceil_div(N, 256) < 512;
+  g.tiles_m = (int)ceil_div(M, BM);
+  g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
+  const bool bkc = transB != 0;
+  if (out_dtype == LDM_BF16)
+    return use128 ? dispatch_layout<128, bf16_t, 0>(g, true, bkc, s) : dispatch_layout<256, bf16_t, 0>(g, true, bkc, s);
+  if (out_dtype == LDM_F32)
+    return use128 ? dispatch_layout<128, float, 0>(g, true, bkc, s) : dispatch_layout<256, float, 0>(g, true, bkc, s);
+  return LDM_E_DTYPE;
+}
+
+int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                                   const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                                   const int *dyn_k, hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
+  if (rc) return rc;
+  if (M < 256 || N < 128) return LDM_E_SHAPE;
+  const bool use128 = N < 256 || (N % 256 != 0 && N % 256 <= 128);
+  g.tiles_m = (int)ceil_div(M, BM);
+  g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
+  if ((int64_t)g.tiles_m * g.tiles_n < 200) return LDM_E_SHAPE;   // no K split with a device-side K
+  g.dyn_k = dyn_k;
+  const bool akc = !transA, bkc = transB != 0;
+  return use128 ? dispatch_layout<128, float, 1>(g, akc, bkc, s) : dispatch_layout<256, float, 1>(g, akc, bkc, s);
 }
 
 int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,

@@ -21,6 +21,24 @@ PAD_N = 64  # output columns of a projection are padded to this multiple in memo
 # projection backward can consume it in place.
 _ZERO_PADDED: dict[int, int] = {}
 
+# LM-head backward over the participating rows only (no host sync: the row count stays on the
+# device).  _COMPACT_OK holds the data_ptr of projection outputs whose backward can take the
+# compact form; the masked-CE backward then leaves (dlogits_compact, rows, count, dummy) in
+# _COMPACT_GRAD under that pointer and hands autograd a zero-stride dummy of the logits' shape.
+_COMPACT_OK: set[int] = set()
+_COMPACT_GRAD: dict[int, tuple] = {}
+COMPACT_HEAD = True   # set False to force the dense LM-head backward
+COMPACT_STATS = {"used": 0}
+
+
+def _expand_compact(dlc, rows, count, T, n_pad):
+    """Dense [T, n_pad] form of a compact gradient (fallback path; synchronises with the host)."""
+    cnt = int(count.item())
+    g = torch.zeros(T, n_pad, dtype=dlc.dtype, device=dlc.device)
+    if cnt:
+        g[rows[:cnt].long()] = dlc[:cnt]
+    return g
+
 
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
@@ -42,6 +60,7 @@ def _rows2d(x: Tensor) -> Tensor:
 class PackedWeights:
     def __init__(self, weights, biases, dtype: torch.dtype, name: str = "linear"):
         self.name = name
+        self.compact_rows = name == "head"   # its gradient comes from the masked CE: mostly zero rows
         self.weights = list(weights)
         self.biases = list(biases)
         self.dtype = dtype
@@ -118,6 +137,11 @@ class _PackedLinear(torch.autograd.Function):
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.save_for_backward(x2, w)
+        ctx.y_ptr = y.data_ptr()
+        if (COMPACT_HEAD and pack.compact_rows and dt == torch.bfloat16 and T >= 1024 and k >= 128 and k % 8 == 0
+                and x2.stride(0) % 4 == 0 and (pack.n_pad // 256) * ((k + 255) // 256) >= 200):
+            _COMPACT_OK.clear()
+            _COMPACT_OK.add(ctx.y_ptr)
         return y[:, :pack.n] if pack.n != pack.n_pad else y
 
     @staticmethod
@@ -127,6 +151,16 @@ class _PackedLinear(torch.autograd.Function):
         dt = pack.dtype
         T, k = x2.shape
         n, n_pad = pack.n, pack.n_pad
+        entry = _COMPACT_GRAD.pop(ctx.y_ptr, None)
+        if entry is not None:
+            dlc, rows, count, dummy = entry
+            if gy.data_ptr() == dummy.data_ptr() and all(st == 0 for st in gy.stride()):
+                out = _PackedLinear._backward_compact(ctx, x2, w, dlc, rows, count)
+                if out is not None:
+                    return out
+                gy = _expand_compact(dlc, rows, count, T, n_pad)[:, :n]
+            else:   # other gradients were added to the logits' gradient: go dense
+                gy = gy + _expand_compact(dlc, rows, count, T, n_pad)[:, :n].view_as(gy)
         # gradient with the padded row stride and zero padding columns
         row_ok = gy.dtype == dt and gy.stride(-1) == 1 and (T == 1 or gy.stride(0) == n_pad)
         if row_ok and (n_pad == n or _ZERO_PADDED.pop(gy.data_ptr(), None) == n_pad):
@@ -153,6 +187,49 @@ class _PackedLinear(torch.autograd.Function):
             off += ne
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
         return (dx, dres, None, *grads_w, *grads_b)
+
+
+def _backward_compact(ctx, x2, w, dlc, rows, count):
+    """dx, dW, db of a projection from the compact gradient rows (None if the kernels decline)."""
+    pack = ctx.pack
+    lib = N.lib()
+    T, k = x2.shape
+    n_pad = pack.n_pad
+    Tp = _round_up(T, 64)
+    dev = x2.device
+    st = N.stream()
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
+        rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, dlc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
+                                   count.data_ptr(), rows.data_ptr(), st)
+        if rc in (-2, -3):
+            return None
+        N.check(rc, "ldm_gemm_rows_dyn")
+    xc = torch.empty(Tp, k, dtype=torch.bfloat16, device=dev)
+    N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), count.data_ptr(), T, k,
+                                xc.data_ptr(), st), "ldm_gather_rows")
+    dw = torch.zeros(n_pad, k, dtype=torch.float32, device=dev)
+    rc = lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, Tp, dlc.data_ptr(), n_pad, xc.data_ptr(), k, dw.data_ptr(), k,
+                               count.data_ptr(), st)
+    if rc in (-2, -3):
+        return None
+    N.check(rc, "ldm_gemm_acc_kdyn")
+    db = torch.empty(n_pad, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
+    N.check(lib.ldm_colsum_rows_dyn(dlc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
+                                    count.data_ptr(), st), "ldm_colsum_rows_dyn")
+    grads_w, grads_b = [], []
+    off = 0
+    for ne in pack.n_each:
+        grads_w.append(dw[off:off + ne])
+        grads_b.append(db[off:off + ne])
+        off += ne
+    COMPACT_STATS["used"] += 1
+    return (dx, None, None, *grads_w, *grads_b)
+
+
+_PackedLinear._backward_compact = staticmethod(_backward_compact)
 
 
 def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None) -> Tensor:
@@ -348,6 +425,14 @@ class _MaskedCE(torch.autograd.Function):
         N.check(lib.ldm_ce_fwd(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(), N.ptr(mi),
                                int(mask_token_id), N.ptr(mb), N.ptr(av), N.ptr(sw), norm_mode, lse.data_ptr(),
                                tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), N.stream()), "ldm_ce_fwd")
+        ctx.compact = None
+        if (l2.data_ptr() in _COMPACT_OK and l2.dtype == torch.bfloat16 and T > 1 and ld % PAD_N == 0
+                and ld == _round_up(V, PAD_N)):
+            rows = torch.empty(T, dtype=torch.int32, device=dev)
+            cnt = torch.empty(1, dtype=torch.int32, device=dev)
+            N.check(lib.ldm_ce_compact_rows(T, seq, N.ptr(mi), int(mask_token_id), N.ptr(mb), N.ptr(av),
+                                            rows.data_ptr(), cnt.data_ptr(), N.stream()), "ldm_ce_compact_rows")
+            ctx.compact = (rows, cnt)
         ctx.save_for_backward(l2, tg, lse, out)
         ctx.aux = (mi, mb, av, sw, int(mask_token_id), norm_mode, seq, ld, logits.shape, logits.dtype)
         return out[0].clone()
@@ -359,8 +444,19 @@ class _MaskedCE(torch.autograd.Function):
         lib = N.lib()
         T, V = l2.shape
         Vp = _round_up(V, PAD_N)
-        dl = torch.empty(T, Vp, dtype=l2.dtype, device=l2.device)
         g = gout.reshape(1).float().contiguous()
+        if ctx.compact is not None and l2.data_ptr() in _COMPACT_OK:
+            rows, cnt = ctx.compact
+            dlc = torch.empty(_round_up(T, 64), Vp, dtype=l2.dtype, device=l2.device)
+            N.check(lib.ldm_ce_bwd_compact(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(),
+                                           N.ptr(sw), norm_mode, lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(),
+                                           rows.data_ptr(), cnt.data_ptr(), dlc.data_ptr(), Vp, N.stream()),
+                    "ldm_ce_bwd_compact")
+            dummy = torch.zeros(1, dtype=l2.dtype, device=l2.device)
+            _COMPACT_GRAD.clear()
+            _COMPACT_GRAD[l2.data_ptr()] = (dlc, rows, cnt, dummy)
+            return dummy.expand(tuple(shape)), None, None, None, None, None, None, None
+        dl = torch.empty(T, Vp, dtype=l2.dtype, device=l2.device)
         N.check(lib.ldm_ce_bwd(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(), N.ptr(mi),
                                mask_token_id, N.ptr(mb), N.ptr(av), N.ptr(sw), norm_mode, lse.data_ptr(),
                                out[1:2].data_ptr(), g.data_ptr(), dl.data_ptr(), Vp, N.stream()), "ldm_ce_bwd")

@@ -146,3 +146,41 @@ def test_default_shape_bf16_step_and_linearity(dev):
     tr.zero_grad(set_to_none=True)
     (2.0 * variational_lower_bound_loss(tr(masked, att), ids, masked, 103, att)).backward()
     assert rel_err(tr.output_layer.weight.grad, 2.0 * g16["output_layer.weight"]) < 1e-3
+
+
+@pytest.mark.parametrize("p_mask", [0.5, 0.0, 1.0])
+def test_lm_head_backward_over_masked_rows_only(dev, p_mask):
+    """The compact LM-head backward (participating rows only, row count kept on the device)
+    gives the same gradients as the dense one, including for no / all rows participating."""
+    from oracle import step_oracle as so
+    from src import ops
+    from src.loss import variational_lower_bound_loss
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    torch.manual_seed(3)
+    cfg = DiffusionTransformerConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=1, dim_feedforward=256,
+                                     dropout=0.0, layer_norm_eps=1e-12, max_position_embeddings=512)
+    tr = DiffusionTransformer(cfg).to(dev).set_compute_dtype(torch.bfloat16)
+    ids, att = so.synthetic_batch(5, 250, 30522, seed=5, ragged=True)     # T = 1250, not a multiple of 64
+    masked, _ = so.forward_mask(ids, p_mask, torch.rand(ids.shape, generator=torch.Generator().manual_seed(1)))
+    ids, att, masked = ids.to(dev), att.to(dev), masked.to(dev)
+    res = {}
+    used0 = ops.COMPACT_STATS["used"]
+    for compact in (True, False):
+        ops.COMPACT_HEAD = compact
+        try:
+            tr.zero_grad(set_to_none=True)
+            loss = variational_lower_bound_loss(tr(masked, att), ids, masked, 103, att)
+            loss.backward()
+        finally:
+            ops.COMPACT_HEAD = True
+        res[compact] = (loss.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()})
+        if compact:
+            assert ops.COMPACT_STATS["used"] > used0, "compact path was not taken"
+        used0 = ops.COMPACT_STATS["used"]
+    assert res[True][0] == res[False][0]
+    for n, g in res[False][1].items():
+        ref = float(g.norm())
+        if ref == 0.0:
+            assert float(res[True][1][n].abs().max()) == 0.0, n
+        else:
+            assert rel_err(res[True][1][n], g) < 2e-3, n
