@@ -42,7 +42,7 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256;
 constexpr int KH = 32;                 // k depth of a half-tile
-constexpr int LDS_BYTES = 128 * 1024;  // ring (<= 128 KiB) and the epilogue staging (8 x 16 KiB)
+constexpr int LDS_BYTES = 128 * 1024;  // ring of 4 half-tiles (128 or 96 KiB) + 32 KiB epilogue staging (inside slot 3 at BN = 256)
 
 struct MArgs {
   int64_t M, N, K;
@@ -116,7 +116,34 @@ __device__ __forceinline__ bf8_t read_frag(const char *img, int rbase, int lane)
   }
 }
 
-// BN: 256 (waves 2M x 4N, 128x64 per wave) or 128 (waves 4M x 2N, 64x64 per wave)
+// Work item -> (split, tile) with an XCD-aware order: work items w and w+8 land on the same
+// XCD (shared L2), so each of the 8 groups gets a contiguous run of items; tiles are walked
+// in bands of 4 m-tiles.
+struct TileId { int split, tm, tn; };
+__device__ __forceinline__ TileId decode_item(int w, int total, const MArgs &g) {
+  {
+    const int q = total >> 3, r = total & 7, x = w & 7;
+    w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (w >> 3);
+  }
+  const int ntiles = g.tiles_m * g.tiles_n;
+  TileId t;
+  t.split = w / ntiles;
+  w -= t.split * ntiles;
+  const int GM = 4;
+  const int width = GM * g.tiles_n;
+  const int grp = w / width;
+  const int first = grp * GM;
+  const int gsz = (g.tiles_m - first < GM) ? g.tiles_m - first : GM;
+  const int in = w - grp * width;
+  t.tm = first + in % gsz;
+  t.tn = in / gsz;
+  return t;
+}
+
+// BN: 256 (waves 2M x 4N, 128x64 per wave) or 128 (waves 4M x 2N, 64x64 per wave).
+// PERSISTENT: gridDim.x workgroups (one per CU) walk the work items w = blockIdx.x,
+// blockIdx.x + gridDim.x, ...; the LDS-DMA of the NEXT item's first three half-tiles is issued
+// before the epilogue of the current one, so the store tail and the load latency overlap.
 template <bool A_KC, bool B_KC, int BN, typename TO, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   constexpr int WN_ = BN / 64;            // waves along N
@@ -127,172 +154,210 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   constexpr int HT_A = BM * 64, HT_B = BN * 64; // bytes of one half-tile image
   constexpr int HT = HT_A + HT_B;
   constexpr int P = PA + PB;
+  // epilogue staging (8 waves x 4 KiB): ring slot 3 when it is 32 KiB, else behind the ring
+  constexpr int STAGE_OFF = (HT >= 32768) ? 3 * HT : 4 * HT;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
+  const bool late = wave >= 4;
 
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int split = bid / ntiles;
-  bid -= split * ntiles;
-  int tm, tn;
-  {
-    const int GM = 4;
-    const int width = GM * g.tiles_n;
-    const int grp = bid / width;
-    const int first = grp * GM;
-    const int gsz = (g.tiles_m - first < GM) ? g.tiles_m - first : GM;
-    const int in = bid - grp * width;
-    tm = first + in % gsz;
-    tn = in / gsz;
-  }
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int total = g.tiles_m * g.tiles_n * g.splits;
   const int64_t Mdyn = g.dyn_m ? (int64_t)*g.dyn_m : g.M;
-  if (m0 >= Mdyn) return;   // workgroup-uniform: nobody of this workgroup reaches a barrier
   const int64_t Kdyn = g.dyn_k ? (((int64_t)*g.dyn_k + KH - 1) / KH) * KH : g.K;
-
   const int np_total = (int)(Kdyn / KH);
   const int base = np_total / g.splits, rem = np_total % g.splits;
-  const int p_begin = split * base + (split < rem ? split : rem);
-  const int np = base + (split < rem ? 1 : 0);
-
-  const bf16_t *srcA[PA], *srcB[PB];
-  stage_ptrs<A_KC, BM>(g.A, g.lda, m0, Mdyn, wave, lane, srcA);
-  stage_ptrs<B_KC, BN>(g.B, g.ldb, n0, g.N, wave, lane, srcB);
   const int64_t kstepA = A_KC ? KH : (int64_t)KH * g.lda;
   const int64_t kstepB = B_KC ? KH : (int64_t)KH * g.ldb;
 
-  f4_t acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  // first work item of this workgroup whose rows exist
+  int w = blockIdx.x;
+  TileId tid{};
+  while (w < total) {
+    tid = decode_item(w, total, g);
+    if ((int64_t)tid.tm * BM < Mdyn) break;
+    w += gridDim.x;
+  }
+  if (w >= total) return;   // workgroup-uniform
 
-  // prologue: half-tiles 0, 1, 2 in flight; half-tile 0 landed for everybody
+  const bf16_t *srcA[PA], *srcB[PB];
+  int p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
+  int np = base + (tid.split < rem ? 1 : 0);
+  stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
+  stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * BN, g.N, wave, lane, srcB);
 #pragma unroll
   for (int p = 0; p < 3; ++p)
     if (p < np) {
       stage_issue<PA>(srcA, (int64_t)(p_begin + p) * kstepA, smem + p * HT, wave);
       stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
     }
-  if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-  else if (np > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
 
-  // The two halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run ONE
-  // barrier apart: while one half is in its MFMA segment the other reads LDS and issues
-  // LDS-DMA.  The second half takes one extra barrier here and the first half one after
-  // the loop, so every s_barrier below pairs segment R of one half with segment M of the other.
-  const bool late = wave >= 4;
-  if (late) __builtin_amdgcn_s_barrier();
-
-  for (int p = 0; p < np; ++p) {
-    // ---- segment R: retire this wave's pieces of half-tile p+1, read p, refill the slot of p-1
-    if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-    else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char *cur = smem + (p & 3) * HT;
-    bf8_t fa[MI], fb[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) fb[i] = read_frag<B_KC, BN>(cur + HT_A, wn * 64 + i * 16, lane);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_KC, BM>(cur, wm * (MI * 16) + i * 16, lane);
-    if (p + 3 < np) {
-      char *slot = smem + ((p + 3) & 3) * HT;
-      stage_issue<PA>(srcA, (int64_t)(p_begin + p + 3) * kstepA, slot, wave);
-      stage_issue<PB>(srcB, (int64_t)(p_begin + p + 3) * kstepB, slot + HT_A, wave);
+  while (true) {
+    const int64_t m0 = (int64_t)tid.tm * BM, n0 = (int64_t)tid.tn * BN;
+    const int64_t nw = n0 + wn * 64;
+    // bias of this lane's 4 output columns; the empty asm is a use, so the compiler's wait for
+    // the load sits HERE (it drains the three half-tiles in flight, which are needed next
+    // anyway) and not inside the epilogue, where it would drain the next item's prefetch.
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (EPI == 0 && g.bias) {
+      const int64_t n = nw + (lane & 15) * 4;
+      if (n + 3 < g.N) {
+        const float4 t = *reinterpret_cast<const float4 *>(g.bias + n);
+        b0 = t.x; b1 = t.y; b2 = t.z; b3 = t.w;
+      } else {
+        if (n < g.N) b0 = g.bias[n];
+        if (n + 1 < g.N) b1 = g.bias[n + 1];
+        if (n + 2 < g.N) b2 = g.bias[n + 2];
+      }
+      asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of half-tile p are complete
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- segment M
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (!late) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();   // every wave is done with the ring: it becomes the epilogue staging area
 
-  // Epilogue through LDS, 64 rows x 64 columns of fp32 (16 KiB) per wave at a time:
-  // fragments go in as 16-byte pieces at chunk c4 ^ (row & 15), rows come out contiguous.
-  float *cs = reinterpret_cast<float *>(smem + wave * 16384);
-  const int64_t nw = n0 + wn * 64;
+    f4_t acc[NI][MI];
 #pragma unroll
-  for (int half = 0; half < MI / 4; ++half) {
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int j = 0; j < MI; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    // half-tile 0 landed for everybody (also: everybody has left the previous epilogue)
+    if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (np > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // The two halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run ONE
+    // barrier apart: while one half is in its MFMA segment the other reads LDS and issues
+    // LDS-DMA.  The second half takes one extra barrier here and the first half one after
+    // the loop, so every s_barrier below pairs segment R of one half with segment M of the other.
+    if (late) __builtin_amdgcn_s_barrier();
+
+    for (int p = 0; p < np; ++p) {
+      // ---- segment R: retire this wave's pieces of half-tile p+1, read p, refill the slot of p-1
+      if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+      else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const char *cur = smem + (p & 3) * HT;
+      bf8_t fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fb[i] = read_frag<B_KC, BN>(cur + HT_A, wn * 64 + i * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_KC, BM>(cur, wm * (MI * 16) + i * 16, lane);
+      if (p + 3 < np) {
+        char *slot = smem + ((p + 3) & 3) * HT;
+        stage_issue<PA>(srcA, (int64_t)(p_begin + p + 3) * kstepA, slot, wave);
+        stage_issue<PB>(srcB, (int64_t)(p_begin + p + 3) * kstepB, slot + HT_A, wave);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of half-tile p are complete
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- segment M
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    // All reads of the ring are complete for every wave (lgkmcnt(0) before each barrier) and
+    // no LDS-DMA is outstanding: slots 0-2 can take the next item's first half-tiles now.
+
+    const TileId done = tid;
+    int wn_next = w + gridDim.x;
+    while (wn_next < total) {
+      tid = decode_item(wn_next, total, g);
+      if ((int64_t)tid.tm * BM < Mdyn) break;
+      wn_next += gridDim.x;
+    }
+    const bool more = wn_next < total;
+    if (more) {
+      p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
+      np = base + (tid.split < rem ? 1 : 0);
+      stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
+      stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * BN, g.N, wave, lane, srcB);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (p < np) {
+          stage_issue<PA>(srcA, (int64_t)(p_begin + p) * kstepA, smem + p * HT, wave);
+          stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
+        }
+    }
+    (void)done;
+
+    // Epilogue through LDS, 16 rows x 64 columns of fp32 (4 KiB, private to the wave) at a
+    // time: fragments go in as 16-byte pieces at chunk c4 ^ row, rows come out contiguous.
+    float *cs = reinterpret_cast<float *>(smem + STAGE_OFF + wave * 4096);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int row = mi * 16 + (lane & 15);
+        const int row = lane & 15;
         const int c4 = ni * 4 + (lane >> 4);
-        const f4_t a = acc[ni][half * 4 + mi];
-        *reinterpret_cast<float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2)) =
+        const f4_t a = acc[ni][mi];
+        *reinterpret_cast<float4 *>(cs + row * 64 + ((c4 ^ row) << 2)) =
             make_float4(a[0] * g.alpha, a[1] * g.alpha, a[2] * g.alpha, a[3] * g.alpha);
       }
-    const int64_t mw = m0 + wm * (MI * 16) + half * 64;
-    if (EPI == 1) {
-      float *C = (float *)g.C;
-      const int64_t n = nw + lane;
+      const int64_t mw = m0 + wm * (MI * 16) + mi * 16;
+      if (EPI == 1) {
+        float *C = (float *)g.C;
+        const int64_t n = nw + lane;
 #pragma unroll 4
-      for (int row = 0; row < 64; ++row) {
-        const float v = cs[row * 64 + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
-        if (mw + row < Mdyn && n < g.N) atomicAdd(C + (mw + row) * g.ldc + n, v);   // 256 contiguous bytes
-      }
-    } else {
-      TO *C = (TO *)g.C;
-      const TO *R = (const TO *)g.R;
-      const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
-      const int c4 = lane & 15;
-      const int64_t n = nw + c4 * 4;
-      f4 bv{{0.f, 0.f, 0.f, 0.f}};
-      if (g.bias) {
+        for (int row = 0; row < 16; ++row) {
+          const float v = cs[row * 64 + ((((lane >> 2) ^ row) << 2) | (lane & 3))];
+          if (mw + row < Mdyn && n < g.N) atomicAdd(C + (mw + row) * g.ldc + n, v);   // 256 contiguous bytes
+        }
+      } else {
+        TO *C = (TO *)g.C;
+        const TO *R = (const TO *)g.R;
+        const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
+        const int c4 = lane & 15;
+        const int64_t n = nw + c4 * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < g.N) bv.v[j] = g.bias[n + j];
-      }
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2));
-        int64_t m = mw + row;
-        if (m >= Mdyn || n >= g.N) continue;
-        if (g.row_map) m = g.row_map[m];
-        f4 v{{t.x + bv.v[0], t.y + bv.v[1], t.z + bv.v[2], t.w + bv.v[3]}};
-        if (n + 3 < g.N && vec_ok) {
-          if (R) {
-            const f4 r = ld4(R + m * g.ldr + n);
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 4 + (lane >> 4);
+          const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ row) << 2));
+          int64_t m = mw + row;
+          if (m >= Mdyn || n >= g.N) continue;
+          if (g.row_map) m = g.row_map[m];
+          f4 v{{t.x + b0, t.y + b1, t.z + b2, t.w + b3}};
+          if (n + 3 < g.N && vec_ok) {
+            if (R) {
+              const f4 r = ld4(R + m * g.ldr + n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v.v[j] += r.v[j];
-          }
-          st4(C + m * g.ldc + n, v);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (n + j < g.N) {
-              float x = v.v[j];
-              if (R) x += Elt<TO>::ld(R + m * g.ldr + n + j);
-              Elt<TO>::st(C + m * g.ldc + n + j, x);
+              for (int j = 0; j < 4; ++j) v.v[j] += r.v[j];
             }
+            st4(C + m * g.ldc + n, v);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (n + j < g.N) {
+                float x = v.v[j];
+                if (R) x += Elt<TO>::ld(R + m * g.ldr + n + j);
+                Elt<TO>::st(C + m * g.ldc + n + j, x);
+              }
+          }
         }
       }
     }
+    if (!more) break;
+    w = wn_next;
   }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
 }
 
 template <bool A_KC, bool B_KC, int BN, typename TO, int EPI>
@@ -303,7 +368,8 @@ int launch256(const MArgs &g, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+  const int64_t items = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+  const int64_t nwg = items < num_cus() ? items : num_cus();   // persistent: one workgroup per CU
   hipLaunchKernelGGL((gemm256_k<A_KC, B_KC, BN, TO, EPI>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, s, g);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
