@@ -192,7 +192,8 @@ int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, 
  *                         dlogits [T, ld_d]; rows count..roundup(count,64) are zeroed
  *   ldm_gather_rows     : out[i,:] = x[rows[i],:] (same zero rounding rows); out has
  *                         roundup(max_rows,64) rows
- *   ldm_gemm_rows_dyn   : C[row_map[m], :] = A[m, :K] * opB(B) for m < *m_dev   (BF16, MFMA)
+ *   ldm_gemm_rows_dyn   : C[row_map[m], :] = A[m, :K] * opB(B) (+ bias) for m < *m_dev; row_map may
+ *                         be NULL (identity), bias may be NULL                 (BF16, MFMA)
  *   ldm_gemm_acc_kdyn   : C(fp32) += opA(A) * opB(B) with K = roundup(*k_dev, 32) (BF16, MFMA)
  *   ldm_colsum_rows_dyn : ldm_colsum over the first *m_dev rows
  * The GEMM forms return LDM_E_SHAPE / LDM_E_ALIGN for problems the MFMA kernel does not take. */
@@ -206,7 +207,7 @@ int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int64_t T, int
 int ldm_gather_rows(const void *x, int dtype, int64_t ld, const int32_t *rows, const int32_t *count,
                     int64_t max_rows, int64_t d, void *out, void *stream);
 int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
-                      const void *B, int64_t ldb, void *C, int64_t ldc, const int32_t *m_dev,
+                      const void *B, int64_t ldb, void *C, int64_t ldc, const float *bias, const int32_t *m_dev,
                       const int32_t *row_map, void *stream);
 int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                       const void *B, int64_t ldb, float *C, int64_t ldc, const int32_t *k_dev, void *stream);

@@ -28,7 +28,7 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
                               int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s);
 int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                               const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
-                              const int *dyn_m, const int *row_map, hipStream_t s);
+                              const float *bias, const int *dyn_m, const int *row_map, hipStream_t s);
 int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                                    const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
                                    const int *dyn_k, hipStream_t s);

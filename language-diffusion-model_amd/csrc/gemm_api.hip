@@ -57,10 +57,11 @@ extern "C" int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int
 
 extern "C" int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K, const void *A,
                                  int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
-                                 const int32_t *m_dev, const int32_t *row_map, void *stream) {
+                                 const float *bias, const int32_t *m_dev, const int32_t *row_map,
+                                 void *stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !m_dev) return LDM_E_BADARG;
-  return ldm_gemm_mfma256_bf16_dyn(out_dtype, 0, transB, M, N, K, 1.0f, A, lda, B, ldb, C, ldc, m_dev, row_map,
-                                   (hipStream_t)stream);
+  return ldm_gemm_mfma256_bf16_dyn(out_dtype, 0, transB, M, N, K, 1.0f, A, lda, B, ldb, C, ldc, bias, m_dev,
+                                   row_map, (hipStream_t)stream);
 }
 
 extern "C" int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, const void *A,
@@ -82,7 +83,7 @@ extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int tra
                           sc, nullptr, nullptr, 0, batch, batch_inner, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 1; }
+extern "C" int ldm_abi_version(void) { return 2; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

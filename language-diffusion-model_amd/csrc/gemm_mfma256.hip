@@ -120,20 +120,20 @@ __device__ __forceinline__ bf8_t read_frag(const char *img, int rbase, int lane)
 // XCD (shared L2), so each of the 8 groups gets a contiguous run of items; tiles are walked
 // in bands of 4 m-tiles.
 struct TileId { int split, tm, tn; };
-__device__ __forceinline__ TileId decode_item(int w, int total, const MArgs &g) {
+__device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int tiles_n) {
   {
     const int q = total >> 3, r = total & 7, x = w & 7;
     w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (w >> 3);
   }
-  const int ntiles = g.tiles_m * g.tiles_n;
+  const int ntiles = tiles_m * tiles_n;
   TileId t;
   t.split = w / ntiles;
   w -= t.split * ntiles;
   const int GM = 4;
-  const int width = GM * g.tiles_n;
+  const int width = GM * tiles_n;
   const int grp = w / width;
   const int first = grp * GM;
-  const int gsz = (g.tiles_m - first < GM) ? g.tiles_m - first : GM;
+  const int gsz = (tiles_m - first < GM) ? tiles_m - first : GM;
   const int in = w - grp * width;
   t.tm = first + in % gsz;
   t.tn = in / gsz;
@@ -163,23 +163,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   const int wm = wave / WN_, wn = wave % WN_;
   const bool late = wave >= 4;
 
-  const int total = g.tiles_m * g.tiles_n * g.splits;
   const int64_t Mdyn = g.dyn_m ? (int64_t)*g.dyn_m : g.M;
+  // with a device-side row count only the m-tiles that hold rows are walked
+  const int tiles_m = (int)((Mdyn + BM - 1) / BM) < g.tiles_m ? (int)((Mdyn + BM - 1) / BM) : g.tiles_m;
+  const int total = tiles_m * g.tiles_n * g.splits;
   const int64_t Kdyn = g.dyn_k ? (((int64_t)*g.dyn_k + KH - 1) / KH) * KH : g.K;
   const int np_total = (int)(Kdyn / KH);
   const int base = np_total / g.splits, rem = np_total % g.splits;
   const int64_t kstepA = A_KC ? KH : (int64_t)KH * g.lda;
   const int64_t kstepB = B_KC ? KH : (int64_t)KH * g.ldb;
 
-  // first work item of this workgroup whose rows exist
   int w = blockIdx.x;
-  TileId tid{};
-  while (w < total) {
-    tid = decode_item(w, total, g);
-    if ((int64_t)tid.tm * BM < Mdyn) break;
-    w += gridDim.x;
-  }
   if (w >= total) return;   // workgroup-uniform
+  TileId tid = decode_item(w, total, tiles_m, g.tiles_n);
 
   const bf16_t *srcA[PA], *srcB[PB];
   int p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
@@ -266,15 +262,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // All reads of the ring are complete for every wave (lgkmcnt(0) before each barrier) and
     // no LDS-DMA is outstanding: slots 0-2 can take the next item's first half-tiles now.
 
-    const TileId done = tid;
-    int wn_next = w + gridDim.x;
-    while (wn_next < total) {
-      tid = decode_item(wn_next, total, g);
-      if ((int64_t)tid.tm * BM < Mdyn) break;
-      wn_next += gridDim.x;
-    }
-    const bool more = wn_next < total;
+    w += gridDim.x;
+    const bool more = w < total;
     if (more) {
+      tid = decode_item(w, total, tiles_m, g.tiles_n);
       p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
       np = base + (tid.split < rem ? 1 : 0);
       stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
@@ -286,7 +277,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
         }
     }
-    (void)done;
 
     // Epilogue through LDS, 16 rows x 64 columns of fp32 (4 KiB, private to the wave) at a
     // time: fragments go in as 16-byte pieces at chunk c4 ^ row, rows come out contiguous.
@@ -344,7 +334,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       }
     }
     if (!more) break;
-    w = wn_next;
   }
 }
 
@@ -434,13 +423,15 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
 // masked rows.  dyn_m/row_map apply to the store form, dyn_k to the accumulate form.
 int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                               const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
-                              const int *dyn_m, const int *row_map, hipStream_t s) {
+                              const float *bias, const int *dyn_m, const int *row_map, hipStream_t s) {
   MArgs g;
-  const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
+  const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, nullptr, 0);
   if (rc) return rc;
   if (transA || M < 256 || N < 128) return LDM_E_SHAPE;
   g.dyn_m = dyn_m; g.row_map = row_map;
-  const bool use128 = N < 256 || (N % 256 != 0 && N % 256 <= 128) || ceil_div(M, BM) * ceil_div(N, 256) < 512;
+  // 128-wide tiles only where a 256-wide last column would waste a visible share of the work
+  const bool use128 = N < 256 || (N % 256 != 0 && N % 256 <= 128 && N < 4096) ||
+                      ceil_div(M, BM) * ceil_div(N, 256) < 512;
   g.tiles_m = (int)ceil_div(M, BM);
   g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
   const bool bkc = transB != 0;

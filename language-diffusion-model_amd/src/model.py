@@ -36,6 +36,20 @@ class DiffusionLanguageModel(nn.Module):
         logits = self.transformer(input_ids=masked_input_ids, attention_mask=attention_mask)
         return logits, masked_input_ids, mask_indices
 
+    def training_loss(self, input_ids: Tensor, attention_mask: Tensor | None = None,
+                      t: Tensor | None = None) -> Tensor:
+        """The loss of one training step: forward() followed by variational_lower_bound_loss
+        as the reference trainer composes them (src/trainer.py:126-134), with the LM head
+        evaluated only at the positions the loss reads.  Consumes the python RNG exactly as
+        forward() does (one random.random() per call)."""
+        if t is None:
+            mask_prob = random.random()
+        else:
+            mask_prob = t.item() if (isinstance(t, torch.Tensor) and t.numel() == 1) else t
+        masked_input_ids, _ = self.masking_strategy.apply_random_mask(input_ids=input_ids, mask_prob=mask_prob)
+        return self.transformer.masked_token_loss(masked_input_ids, input_ids, self.tokenizer.mask_token_id,
+                                                  attention_mask)
+
     def generate(self, *args, **kwargs):
         raise NotImplementedError("reverse-process generation (src/model.py:74-106) is outside the "
                                   "training-step scope of this package")

@@ -202,7 +202,7 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
     if ctx.needs_input_grad[0]:
         dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
         rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, dlc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
-                                   count.data_ptr(), rows.data_ptr(), st)
+                                   None, count.data_ptr(), rows.data_ptr(), st)
         if rc in (-2, -3):
             return None
         N.check(rc, "ldm_gemm_rows_dyn")
@@ -469,6 +469,122 @@ class _MaskedCE(torch.autograd.Function):
             _ZERO_PADDED.clear()
             _ZERO_PADDED[dl.data_ptr()] = Vp
         return d, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------
+FUSED_HEAD_LOSS = True   # set False to always materialise the full [T, V] logits in the training step
+FUSED_HEAD_STATS = {"used": 0}
+
+
+def head_loss_eligible(x2: Tensor, pack: PackedWeights) -> bool:
+    """Whether head_masked_ce can take this problem (bf16 MFMA forms with device-side sizes)."""
+    T, k = x2.shape
+    return (FUSED_HEAD_LOSS and pack.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and T >= 1024
+            and k >= 128 and k % 32 == 0 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0
+            and (pack.n_pad // 256) * ((k + 255) // 256) >= 200)
+
+
+class _HeadMaskedCE(torch.autograd.Function):
+    """mean CE over the participating rows of (x @ W^T + b) without forming the other rows.
+
+    The vocabulary projection (src/transformer.py:441) followed by
+    variational_lower_bound_loss (src/loss.py:59-65) reads only the logits of positions whose
+    masked id is the mask token (and attention_mask == 1).  Forward: compact those rows of x,
+    one GEMM over them (row count on the device, no host sync), streamed log-sum-exp.
+    Backward: softmax-minus-one-hot written over the compact logits in place, then dx (scattered
+    back to the source rows), dW and db from the compact rows.  Loss and every gradient equal
+    the dense computation's: the skipped rows contribute exact zeros there."""
+
+    @staticmethod
+    def forward(ctx, x2, pack: PackedWeights, targets, masked_ids, att_valid, mask_token_id, *params):
+        N.require_device(x2)
+        lib = N.lib()
+        st = N.stream()
+        w, b = pack.get()
+        T, k = x2.shape
+        dev = x2.device
+        n_pad = pack.n_pad
+        Tp = _round_up(T, 256)
+        tg = targets.reshape(-1).contiguous()
+        mi = masked_ids.reshape(-1).contiguous()
+        av = att_valid.reshape(-1).contiguous().view(torch.uint8) if att_valid is not None else None
+        rows = torch.zeros(T, dtype=torch.int32, device=dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=dev)
+        N.check(lib.ldm_ce_compact_rows(T, 1, mi.data_ptr(), int(mask_token_id), None, N.ptr(av), rows.data_ptr(),
+                                        cnt.data_ptr(), st), "ldm_ce_compact_rows")
+        xc = torch.empty(Tp, k, dtype=torch.bfloat16, device=dev)
+        N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), cnt.data_ptr(), T, k,
+                                    xc.data_ptr(), st), "ldm_gather_rows")
+        tgc = tg[rows.long()]                                       # entries past the count repeat row 0: unused
+        valid = torch.arange(T, dtype=torch.int32, device=dev) < cnt  # compact row i exists
+        lc = torch.empty(Tp, n_pad, dtype=torch.bfloat16, device=dev)
+        ev = GEMM_EVENTS.get("head.fwd") if GEMM_EVENTS is not None else None
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        N.check(lib.ldm_gemm_rows_dyn(N.BF16, 1, T, n_pad, k, xc.data_ptr(), k, w.data_ptr(), k, lc.data_ptr(), n_pad,
+                                      b.data_ptr(), cnt.data_ptr(), None, st), "ldm_gemm_rows_dyn")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, 2.0 * n_pad * k, cnt))              # flops per row; rows = cnt (device)
+        lse = torch.empty(T, dtype=torch.float32, device=dev)
+        tmp = torch.empty(T, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        N.check(lib.ldm_ce_fwd(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
+                               valid.view(torch.uint8).data_ptr(), None, None, 0, lse.data_ptr(), tmp.data_ptr(),
+                               out[0:1].data_ptr(), out[1:2].data_ptr(), st), "ldm_ce_fwd")
+        ctx.pack = pack
+        ctx.save_for_backward(xc, w, lc, tgc, lse, out, rows, cnt)
+        ctx.dims = (T, k)
+        ctx.done = False
+        FUSED_HEAD_STATS["used"] += 1
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.done:
+            raise RuntimeError("the fused LM-head loss overwrites its logits in backward: backward twice "
+                               "through the same forward is not supported")
+        ctx.done = True
+        xc, w, lc, tgc, lse, out, rows, cnt = ctx.saved_tensors
+        pack = ctx.pack
+        lib = N.lib()
+        st = N.stream()
+        T, k = ctx.dims
+        n_pad = pack.n_pad
+        dev = xc.device
+        g = gout.reshape(1).float().contiguous()
+        ident = torch.arange(T, dtype=torch.int32, device=dev)
+        # dlogits over the logits, in place (each element is read and written by the same thread)
+        N.check(lib.ldm_ce_bwd_compact(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
+                                       lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(), ident.data_ptr(),
+                                       cnt.data_ptr(), lc.data_ptr(), n_pad, st), "ldm_ce_bwd_compact")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
+            N.check(lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, lc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(),
+                                          k, None, cnt.data_ptr(), rows.data_ptr(), st), "ldm_gemm_rows_dyn")
+        dw = torch.zeros(n_pad, k, dtype=torch.float32, device=dev)
+        N.check(lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, _round_up(T, 64), lc.data_ptr(), n_pad, xc.data_ptr(), k,
+                                      dw.data_ptr(), k, cnt.data_ptr(), st), "ldm_gemm_acc_kdyn")
+        db = torch.empty(n_pad, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
+        N.check(lib.ldm_colsum_rows_dyn(lc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
+                                        cnt.data_ptr(), st), "ldm_colsum_rows_dyn")
+        grads_w, grads_b = [], []
+        off = 0
+        for ne in pack.n_each:
+            grads_w.append(dw[off:off + ne])
+            grads_b.append(db[off:off + ne])
+            off += ne
+        return (dx, None, None, None, None, None, *grads_w, *grads_b)
+
+
+def head_masked_ce(x: Tensor, pack: PackedWeights, targets: Tensor, masked_ids: Tensor, mask_token_id: int,
+                   att_valid: Tensor | None = None) -> Tensor:
+    """variational_lower_bound_loss(linear(x), ...) computed on the participating rows only."""
+    x2 = _rows2d(x)
+    return _HeadMaskedCE.apply(x2, pack, targets, masked_ids, att_valid, mask_token_id, *pack.weights, *pack.biases)
 
 
 def _padded_strides(shape, ld):

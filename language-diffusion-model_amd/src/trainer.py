@@ -23,15 +23,21 @@ class DiffusionLanguageModelTrainer:
         self.accelerator = accelerator
         self.history: list[float] = []
         self.global_step = 0
+        self.fused_head_loss = True   # False: model() then variational_lower_bound_loss(), as the reference spells it
 
     def _step(self, batch) -> torch.Tensor:
         input_ids = batch["input_ids"]
         attention_mask = batch.get("attention_mask", None)
         self.optimizer.zero_grad()
-        logits, masked_input_ids, _ = self.model(input_ids=input_ids, attention_mask=attention_mask)
-        loss = variational_lower_bound_loss(logits=logits, targets=input_ids, masked_input_ids=masked_input_ids,
-                                            attention_mask=attention_mask,
-                                            mask_token_id=self.model.tokenizer.mask_token_id)
+        if self.fused_head_loss and hasattr(self.model, "training_loss"):
+            # same value and gradients as the two calls below; the logits of positions the loss
+            # never reads are not formed
+            loss = self.model.training_loss(input_ids=input_ids, attention_mask=attention_mask)
+        else:
+            logits, masked_input_ids, _ = self.model(input_ids=input_ids, attention_mask=attention_mask)
+            loss = variational_lower_bound_loss(logits=logits, targets=input_ids,
+                                                masked_input_ids=masked_input_ids, attention_mask=attention_mask,
+                                                mask_token_id=self.model.tokenizer.mask_token_id)
         self.accelerator.backward(loss)
         self.optimizer.step()
         self.global_step += 1

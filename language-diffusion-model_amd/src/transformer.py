@@ -273,19 +273,39 @@ class DiffusionTransformer(nn.Module):
             self._packs[key] = ops.PackedWeights([self.output_layer.weight], [self.output_layer.bias], key, "head")
         return self._packs[key]
 
-    def forward(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:
-        """input_ids [B,S] (+ attention_mask [B,S]) -> logits [B,S,V] in compute_dtype.
-
-        The logits rows are stored with a stride padded to 64 columns; the returned
-        tensor is the [B,S,V] view of that buffer."""
+    def hidden_states(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:
+        """Everything of forward() up to and including the final norm: [B,S,d]."""
         x = ops.embedding(input_ids, self.embedding.weight, self.compute_dtype, self.hot_token_id)
         key_padding_mask = None
         if attention_mask is not None:
             key_padding_mask = attention_mask == 0
         for layer in self.layers:
             x = layer(x, src_key_padding_mask=key_padding_mask)
-        x = self.norm(x)
-        return ops.packed_linear(x, self._head_pack())
+        return self.norm(x)
+
+    def forward(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:
+        """input_ids [B,S] (+ attention_mask [B,S]) -> logits [B,S,V] in compute_dtype.
+
+        The logits rows are stored with a stride padded to 64 columns; the returned
+        tensor is the [B,S,V] view of that buffer."""
+        return ops.packed_linear(self.hidden_states(input_ids, attention_mask), self._head_pack())
+
+    def masked_token_loss(self, masked_input_ids: Tensor, targets: Tensor, mask_token_id: int,
+                          attention_mask: Tensor | None = None) -> Tensor:
+        """variational_lower_bound_loss(self(masked_input_ids, attention_mask), targets, ...)
+        (src/loss.py:31-65 on src/transformer.py:413-444) without the logits of positions the
+        loss does not read; falls back to exactly that composition when the fused kernels do
+        not take the problem."""
+        from .loss import variational_lower_bound_loss
+        x = self.hidden_states(masked_input_ids, attention_mask)
+        pack = self._head_pack()
+        x2 = x.reshape(-1, x.shape[-1])
+        if ops.head_loss_eligible(x2, pack):
+            att_valid = (attention_mask == 1) if attention_mask is not None else None
+            return ops.head_masked_ce(x2, pack, targets, masked_input_ids, mask_token_id, att_valid)
+        logits = ops.packed_linear(x, pack)
+        return variational_lower_bound_loss(logits=logits, targets=targets, masked_input_ids=masked_input_ids,
+                                            mask_token_id=mask_token_id, attention_mask=attention_mask)
 
 
 __all__ = ["DiffusionTransformerConfig", "RMSNorm", "SwiGLU", "rotate_half", "RotaryPositionEmbedding",

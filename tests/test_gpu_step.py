@@ -184,3 +184,56 @@ def test_lm_head_backward_over_masked_rows_only(dev, p_mask):
             assert float(res[True][1][n].abs().max()) == 0.0, n
         else:
             assert rel_err(res[True][1][n], g) < 2e-3, n
+
+
+@pytest.mark.parametrize("p_mask", [0.5, 0.0, 1.0])
+def test_fused_head_loss_equals_dense_composition(dev, p_mask):
+    """masked_token_loss (LM head evaluated on the participating rows only, forward and
+    backward) equals variational_lower_bound_loss(transformer(...)) in loss and every gradient,
+    including for no / all rows participating; both are checked against the fp32 oracle."""
+    from oracle import step_oracle as so
+    from src import ops
+    from src.loss import variational_lower_bound_loss
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    torch.manual_seed(3)
+    cfg = DiffusionTransformerConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=1, dim_feedforward=256,
+                                     dropout=0.0, layer_norm_eps=1e-12, max_position_embeddings=512)
+    tr = DiffusionTransformer(cfg).to(dev).set_compute_dtype(torch.bfloat16)
+    ids, att = so.synthetic_batch(5, 250, 30522, seed=5, ragged=True)     # T = 1250, not a multiple of 64
+    masked, _ = so.forward_mask(ids, p_mask, torch.rand(ids.shape, generator=torch.Generator().manual_seed(1)))
+    ocfg = so.OracleConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=1, dim_feedforward=256,
+                           layer_norm_eps=1e-12)
+    oparams = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in tr.state_dict().items()
+               if k in dict(tr.named_parameters())}
+    ologits = so.transformer_forward(oparams, ocfg, masked, att)
+    oloss = so.vlb_loss(ologits, ids, masked, 103, att)
+    if oloss.grad_fn is not None:
+        oloss.backward()
+    ids, att, masked = ids.to(dev), att.to(dev), masked.to(dev)
+    res = {}
+    for fused in (True, False):
+        tr.zero_grad(set_to_none=True)
+        used0 = ops.FUSED_HEAD_STATS["used"]
+        if fused:
+            loss = tr.masked_token_loss(masked, ids, 103, att)
+            assert ops.FUSED_HEAD_STATS["used"] == used0 + 1, "fused path was not taken"
+        else:
+            loss = variational_lower_bound_loss(tr(masked, att), ids, masked, 103, att)
+        loss.backward()
+        res[fused] = (loss.item(), {n: (p.grad.detach().clone() if p.grad is not None else None)
+                                   for n, p in tr.named_parameters()})
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * max(1.0, abs(res[False][0]))
+    assert abs(res[True][0] - float(oloss)) <= 2e-2 * max(1e-6, abs(float(oloss)))
+    for n, g in res[False][1].items():
+        gf = res[True][1][n]
+        if g is None or float(g.norm()) == 0.0:
+            assert gf is None or float(gf.abs().max()) == 0.0, n
+            continue
+        assert rel_err(gf, g) < 2e-3, n
+    if oloss.grad_fn is not None:
+        # bf16 compute against the fp32 oracle: relative error of the whole gradient vector
+        # (single near-zero tensors such as the key bias are dominated by bf16 rounding)
+        names = [n for n, _ in tr.named_parameters()]
+        mine = torch.cat([res[True][1][n].float().cpu().reshape(-1) for n in names])
+        ref = torch.cat([oparams[n].grad.reshape(-1) for n in names])
+        assert rel_err(mine, ref) < 2e-2
