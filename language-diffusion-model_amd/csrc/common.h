@@ -17,12 +17,17 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned)v) << 16);
 }
 
-// round-to-nearest-even; NaN stays NaN (quiet)
+// round-to-nearest-even, NaN stays a quiet NaN: the gfx950 packed convert (v_cvt_pk_bf16_f32)
+typedef __bf16 ldm_bf2_t __attribute__((ext_vector_type(2)));
+typedef float ldm_fl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const ldm_fl2_t f{lo, hi};
+  const ldm_bf2_t h = __builtin_convertvector(f, ldm_bf2_t);
+  return __builtin_bit_cast(unsigned, h);
+}
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
 }
 
 template <typename T> struct Elt;
@@ -51,10 +56,43 @@ __device__ __forceinline__ void st4(float *p, const f4 &a) {
 }
 __device__ __forceinline__ void st4(bf16_t *p, const f4 &a) {
   uint2 t;
-  t.x = (unsigned)f32_to_bf16(a.v[0]) | ((unsigned)f32_to_bf16(a.v[1]) << 16);
-  t.y = (unsigned)f32_to_bf16(a.v[2]) | ((unsigned)f32_to_bf16(a.v[3]) << 16);
+  t.x = pack_bf16x2(a.v[0], a.v[1]);
+  t.y = pack_bf16x2(a.v[2], a.v[3]);
   *reinterpret_cast<uint2 *>(p) = t;
 }
+
+// 8 consecutive elements kept in their storage form (16 B for bf16, 32 B for float)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 u;
+  __device__ __forceinline__ void load(const bf16_t *p) { u = *reinterpret_cast<const uint4 *>(p); }
+  __device__ __forceinline__ float get(int j) const {
+    const unsigned w = j < 2 ? u.x : j < 4 ? u.y : j < 6 ? u.z : u.w;
+    return (j & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+  }
+  static __device__ __forceinline__ void store(bf16_t *p, const float (&o)[8]) {
+    uint4 t;
+    t.x = pack_bf16x2(o[0], o[1]);
+    t.y = pack_bf16x2(o[2], o[3]);
+    t.z = pack_bf16x2(o[4], o[5]);
+    t.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4 *>(p) = t;
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float *p) {
+    a = *reinterpret_cast<const float4 *>(p);
+    b = *reinterpret_cast<const float4 *>(p + 4);
+  }
+  __device__ __forceinline__ float get(int j) const {
+    return j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : j == 3 ? a.w : j == 4 ? b.x : j == 5 ? b.y : j == 6 ? b.z : b.w;
+  }
+  static __device__ __forceinline__ void store(float *p, const float (&o)[8]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4 *>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

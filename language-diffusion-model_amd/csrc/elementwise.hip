@@ -163,6 +163,122 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T *x, const float *w,
     dw_partial[(int64_t)blockIdx.x * d + c] = smem[c] + smem[d + c] + smem[2 * d + c] + smem[3 * d + c];
 }
 
+// 8-element-vector forms (d % 8 == 0): 16-byte accesses for bf16, every load of a row issued
+// before the first use, rows kept in storage form in registers.  NV = vectors per lane.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd8_k(const T *x, const float *w, int64_t rows, int d, float eps,
+                                                      T *y, float *rstd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = d >> 3;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const T *xr = x + r * d;
+    Raw8<T> v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + i * 64 < nvec) v[i].load(xr + (lane + i * 64) * 8);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + i * 64 < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss = fmaf(v[i].get(j), v[i].get(j), ss);
+      }
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)d + eps);
+    if (lane == 0) rstd[r] = rs;
+    T *yr = y + r * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        const f4 g0 = ld4(w + vi * 8), g1 = ld4(w + vi * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = g0.v[j] * (v[i].get(j) * rs);
+          o[j + 4] = g1.v[j] * (v[i].get(j + 4) * rs);
+        }
+        Raw8<T>::store(yr + vi * 8, o);
+      }
+    }
+  }
+}
+
+template <typename T, int NV, bool RES>
+__global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w, const float *rstd, const T *dy,
+                                                      const T *dres, int64_t rows, int d, T *dx,
+                                                      float *dw_partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][d]
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = d >> 3;
+  float wv[NV][8], acc[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = lane + i * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[i][j] = 0.f;
+      wv[i][j] = (vi < nvec) ? w[vi * 8 + j] : 0.f;
+    }
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float rs = rstd[r];
+    Raw8<T> xv[NV], gv[NV], rv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        xv[i].load(x + r * d + vi * 8);
+        gv[i].load(dy + r * d + vi * 8);
+        if (RES) rv[i].load(dres + r * d + vi * 8);
+      }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + i * 64 < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xx = xv[i].get(j), gg = gv[i].get(j);
+          acc[i][j] = fmaf(gg, xx * rs, acc[i][j]);
+          dot = fmaf(gg * wv[i][j], xx, dot);
+        }
+      }
+    dot = wave_sum(dot);
+    const float k = dot * rs * rs * rs * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o[j] = fmaf(rs, gv[i].get(j) * wv[i][j], -xv[i].get(j) * k);
+          if (RES) o[j] += rv[i].get(j);
+        }
+        Raw8<T>::store(dx + r * d + vi * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) smem[wid * d + vi * 8 + j] = acc[i][j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    dw_partial[(int64_t)blockIdx.x * d + c] = smem[c] + smem[d + c] + smem[2 * d + c] + smem[3 * d + c];
+}
+
 // out[c] = sum_p partial[p][c]   (deterministic second stage)
 // Block = 32 columns x 8 partial lanes; each lane strides over the partials, LDS joins them.
 __global__ __launch_bounds__(256) void reduce_partials_k(const float *partial, int64_t nparts, int64_t d,
@@ -378,7 +494,14 @@ inline int rms_nv(int64_t d) {
   return nv;
 }
 
-constexpr int kRmsBwdBlocks = 512;   // rows of the dw partial workspace
+constexpr int kRmsBwdBlocks = 2048;  // rows of the dw partial workspace (8 workgroups per CU resident)
+
+inline int rms_nv8(int64_t d) {
+  const int64_t need = ceil_div(d / 8, 64);
+  int nv = 1;
+  while (nv < need) nv <<= 1;
+  return nv;
+}
 
 }  // namespace
 
@@ -426,6 +549,17 @@ static int rmsnorm_fwd_launch(const void *x, const float *w, int64_t rows, int64
   const unsigned grid = stream_grid(rows, 4);
   const T *xx = (const T *)x;
   T *yy = (T *)y;
+  if (d % 8 == 0 && aligned_to(w, 16) && rms_nv8(d) <= 4) {
+#define RMS_F8(NV) hipLaunchKernelGGL((rmsnorm_fwd8_k<T, NV>), dim3(grid), dim3(256), 0, s, xx, w, rows, (int)d, eps, yy, rstd)
+    switch (rms_nv8(d)) {
+      case 1: RMS_F8(1); break;
+      case 2: RMS_F8(2); break;
+      default: RMS_F8(4); break;
+    }
+#undef RMS_F8
+    LDM_CHECK_LAUNCH();
+    return LDM_OK;
+  }
 #define RMS_F(NV) hipLaunchKernelGGL((rmsnorm_fwd_k<T, NV>), dim3(grid), dim3(256), 0, s, xx, w, rows, (int)d, eps, yy, rstd)
   switch (rms_nv(d)) {
     case 1: RMS_F(1); break;
@@ -467,6 +601,28 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
   if (blocks > kRmsBwdBlocks) blocks = kRmsBwdBlocks;
   const unsigned grid = (unsigned)blocks;
   const size_t lds = (size_t)4 * d * sizeof(float);
+  if (d % 8 == 0 && rms_nv8(d) <= 4) {
+#define RMS_B8(NV)                                                                                                \
+  do {                                                                                                            \
+    if (dres)                                                                                                     \
+      hipLaunchKernelGGL((rmsnorm_bwd8_k<T, NV, true>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,      \
+                         (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial);                      \
+    else                                                                                                          \
+      hipLaunchKernelGGL((rmsnorm_bwd8_k<T, NV, false>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,     \
+                         (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial);                      \
+  } while (0)
+    switch (rms_nv8(d)) {
+      case 1: RMS_B8(1); break;
+      case 2: RMS_B8(2); break;
+      default: RMS_B8(4); break;
+    }
+#undef RMS_B8
+    LDM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(256), 0, s, dw_partial,
+                       (int64_t)grid, d, dw);
+    LDM_CHECK_LAUNCH();
+    return LDM_OK;
+  }
 #define RMS_B(NV)                                                                                      \
   hipLaunchKernelGGL((rmsnorm_bwd_k<T, NV>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,      \
                      (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial)

@@ -310,6 +310,54 @@ def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
     return _RMSNorm.apply(x, weight, eps)
 
 
+class _RMSNormRes(torch.autograd.Function):
+    """(y, x) = (rms_norm(x), x): the second output carries the residual stream, so that the
+    gradient arriving through the residual connection is added inside the norm's backward
+    kernel instead of by a separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        N.require_device(x, weight)
+        xc = x.contiguous()
+        d = xc.shape[-1]
+        T = xc.numel() // d
+        y = torch.empty_like(xc)
+        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+        w = weight.detach().float().contiguous()
+        N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
+                                        y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+        ctx.save_for_backward(xc, w, rstd)
+        return y, xc.view_as(xc)
+
+    @staticmethod
+    def backward(ctx, gy, gres):
+        xc, w, rstd = ctx.saved_tensors
+        if gy is None:
+            return gres, None, None
+        d = xc.shape[-1]
+        T = xc.numel() // d
+        g = gy.contiguous()
+        if g.dtype != xc.dtype:
+            g = g.to(xc.dtype)
+        r = None
+        if gres is not None:
+            r = gres.contiguous()
+            if r.dtype != xc.dtype:
+                r = r.to(xc.dtype)
+        dx = torch.empty_like(xc)
+        dw = torch.empty(d, dtype=torch.float32, device=xc.device)
+        ws = torch.empty(N.lib().ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
+        N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
+                                        N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                        N.stream()), "ldm_rmsnorm_bwd")
+        return dx, dw, None
+
+
+def rms_norm_with_residual(x: Tensor, weight: Tensor, eps: float) -> tuple[Tensor, Tensor]:
+    """(rms_norm(x), x); use the second value as the residual-connection operand."""
+    return _RMSNormRes.apply(x, weight, eps)
+
+
 # ----------------------------------------------------------------------------
 class _SwiGLUAct(torch.autograd.Function):
     @staticmethod

@@ -64,6 +64,11 @@ class RMSNorm(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         return ops.rms_norm(x, self.weight, self.eps)
 
+    def with_residual(self, x: Tensor) -> tuple[Tensor, Tensor]:
+        """(norm(x), x): feeding the second value to the residual connection lets the norm's
+        backward kernel add the residual-stream gradient itself."""
+        return ops.rms_norm_with_residual(x, self.weight, self.eps)
+
 
 class SwiGLU(nn.Module):
     """w3( w1(x) * silu(w2(x)) ) -- the gate is w2 (src/transformer.py:91-95)."""
@@ -212,20 +217,20 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src: Tensor, src_mask: Tensor | None = None,
                 src_key_padding_mask: Tensor | None = None) -> Tensor:
         drop = self.training and self.dropout.p > 0
-        src_norm = self.norm1(src)
         if drop:
+            src_norm = self.norm1(src)
             attn_output = self.self_attn(src_norm, src_norm, src_norm, attn_mask=src_mask,
                                          key_padding_mask=src_key_padding_mask)
             src = src + self.dropout(attn_output)
-        else:  # residual add fused into the out-projection epilogue
-            src = self.self_attn(src_norm, src_norm, src_norm, attn_mask=src_mask,
-                                 key_padding_mask=src_key_padding_mask, residual=src)
-        src_norm = self.norm2(src)
-        if drop:
-            src = src + self.dropout(self.swiglu(src_norm))
-        else:
-            src = self.swiglu(src_norm, residual=src)
-        return src
+            src_norm = self.norm2(src)
+            return src + self.dropout(self.swiglu(src_norm))
+        # residual add fused into the projection epilogue (forward) and into the norm's
+        # backward kernel (gradient of the residual stream)
+        src_norm, src = self.norm1.with_residual(src)
+        src = self.self_attn(src_norm, src_norm, src_norm, attn_mask=src_mask,
+                             key_padding_mask=src_key_padding_mask, residual=src)
+        src_norm, src = self.norm2.with_residual(src)
+        return self.swiglu(src_norm, residual=src)
 
 
 class DiffusionTransformer(nn.Module):
