@@ -122,6 +122,16 @@ int ldm_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int
 int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                  const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
                  void *stream);
+
+/* Weight AND bias gradient of a projection in one pass (nn.Linear backward under autograd,
+ * e.g. src/transformer.py:212-215, 441): C(fp32) += alpha * opA(A) * opB(B) and
+ * a_rowsum[m] (fp32, pre-zeroed by the caller like C) += alpha * sum_k opA(A)[m, k].
+ * With opA(A) = dy^T this is dW += dy^T x and db += column sums of dy.  BF16 MFMA kernels
+ * only: returns LDM_E_SHAPE / LDM_E_ALIGN for problems they do not take (the caller then uses
+ * ldm_gemm_acc + ldm_colsum). */
+int ldm_gemm_acc_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                        const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                        float *a_rowsum, void *stream);
 int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N,
                      int64_t K, float alpha, const void *A, int64_t lda, ldm_bstride sa,
                      const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,
@@ -194,7 +204,8 @@ int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, 
  *                         roundup(max_rows,64) rows
  *   ldm_gemm_rows_dyn   : C[row_map[m], :] = A[m, :K] * opB(B) (+ bias) for m < *m_dev; row_map may
  *                         be NULL (identity), bias may be NULL                 (BF16, MFMA)
- *   ldm_gemm_acc_kdyn   : C(fp32) += opA(A) * opB(B) with K = roundup(*k_dev, 32) (BF16, MFMA)
+ *   ldm_gemm_acc_kdyn   : C(fp32) += opA(A) * opB(B) with K = roundup(*k_dev, 32) (BF16, MFMA);
+ *                         a_rowsum (nullable) as in ldm_gemm_acc_rowsum
  *   ldm_colsum_rows_dyn : ldm_colsum over the first *m_dev rows
  * The GEMM forms return LDM_E_SHAPE / LDM_E_ALIGN for problems the MFMA kernel does not take. */
 int ldm_ce_compact_rows(int64_t T, int64_t seq, const int64_t *masked_ids, int64_t mask_token_id,
@@ -210,7 +221,8 @@ int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K
                       const void *B, int64_t ldb, void *C, int64_t ldc, const float *bias, const int32_t *m_dev,
                       const int32_t *row_map, void *stream);
 int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
-                      const void *B, int64_t ldb, float *C, int64_t ldc, const int32_t *k_dev, void *stream);
+                      const void *B, int64_t ldb, float *C, int64_t ldc, const int32_t *k_dev, float *a_rowsum,
+                      void *stream);
 int ldm_colsum_rows_dyn(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
                         const int32_t *m_dev, void *stream);
 

@@ -13,9 +13,11 @@ int ldm_gemm_mfma_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t
                        const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
                        const float *bias, const void *R, int64_t ldr, hipStream_t s);
 
-// C(fp32) += alpha * opA(A) * opB(B) with the K range split across workgroups (float atomics)
+// C(fp32) += alpha * opA(A) * opB(B) with the K range split across workgroups (float atomics);
+// rowsum (nullable): rowsum[m] += alpha * sum_k opA[m, k]
 int ldm_gemm_mfma_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
-                           int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s);
+                           int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, float *rowsum,
+                           hipStream_t s);
 int ldm_gemm_generic_acc(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                          const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
                          hipStream_t s);
@@ -25,10 +27,11 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
                           const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
                           const float *bias, const void *R, int64_t ldr, hipStream_t s);
 int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
-                              int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s);
+                              int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, float *rowsum,
+                              hipStream_t s);
 int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                               const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
                               const float *bias, const int *dyn_m, const int *row_map, hipStream_t s);
 int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                                    const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
-                                   const int *dyn_k, hipStream_t s);
+                                   const int *dyn_k, float *rowsum, hipStream_t s);

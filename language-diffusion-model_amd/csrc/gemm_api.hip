@@ -47,12 +47,24 @@ extern "C" int ldm_gemm_acc(int in_dtype, int transA, int transB, int64_t M, int
   if (in_dtype == LDM_BF16) {
     int rc = LDM_E_SHAPE;
     if (gemm_kernel_choice() != 128)
-      rc = ldm_gemm_mfma256_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+      rc = ldm_gemm_mfma256_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, s);
     if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
-    rc = ldm_gemm_mfma_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+    rc = ldm_gemm_mfma_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, s);
     if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
   }
   return ldm_gemm_generic_acc(in_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+}
+
+extern "C" int ldm_gemm_acc_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                                   const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
+                                   float *a_rowsum, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !a_rowsum) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = LDM_E_SHAPE;
+  if (gemm_kernel_choice() != 128)
+    rc = ldm_gemm_mfma256_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, a_rowsum, s);
+  if (rc != LDM_E_SHAPE && rc != LDM_E_ALIGN) return rc;
+  return ldm_gemm_mfma_bf16_acc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, a_rowsum, s);
 }
 
 extern "C" int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K, const void *A,
@@ -66,9 +78,9 @@ extern "C" int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N
 
 extern "C" int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, const void *A,
                                  int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
-                                 const int32_t *k_dev, void *stream) {
+                                 const int32_t *k_dev, float *a_rowsum, void *stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !k_dev) return LDM_E_BADARG;
-  return ldm_gemm_mfma256_bf16_acc_dynk(transA, transB, M, N, K, 1.0f, A, lda, B, ldb, C, ldc, k_dev,
+  return ldm_gemm_mfma256_bf16_acc_dynk(transA, transB, M, N, K, 1.0f, A, lda, B, ldb, C, ldc, k_dev, a_rowsum,
                                         (hipStream_t)stream);
 }
 
@@ -83,7 +95,7 @@ extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int tra
                           sc, nullptr, nullptr, 0, batch, batch_inner, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 2; }
+extern "C" int ldm_abi_version(void) { return 3; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

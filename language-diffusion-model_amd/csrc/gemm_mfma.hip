@@ -47,6 +47,7 @@ struct MArgs {
   const float *bias;
   const void *R; int64_t ldr;
   int tiles_m, tiles_n, splits;
+  float *rowsum;   // EPI 1 only: rowsum[m] += alpha * sum_k opA[m, k], by the first tile column
 };
 
 __device__ __forceinline__ int swz_tr(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
@@ -111,7 +112,7 @@ template <bool A_KC, bool B_KC, typename TO, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A tile | B tile]
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: branches on it stay uniform (MFMA ignores EXEC)
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware remap (blocks b and b+8 share an XCD's L2): give each of the 8 groups
@@ -156,6 +157,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
+  // row sums of opA: wave wn of a first-column tile takes fragments mi = 2*wn, 2*wn + 1
+  f4_t racc[2] = {f4_t{0.f, 0.f, 0.f, 0.f}, f4_t{0.f, 0.f, 0.f, 0.f}};
+  const bool do_rowsum = EPI == 1 && g.rowsum != nullptr && tn == 0;
+
   if (nt > 0) {
     stage_issue<A_KC>(srcA, (int64_t)t_begin * kstepA, smem, wave);
     stage_issue<B_KC>(srcB, (int64_t)t_begin * kstepB, smem + TILE_BYTES, wave);
@@ -183,6 +188,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      if (EPI == 1 && do_rowsum) {
+        const bf8_t ones = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          if ((mi >> 1) == wn)
+            racc[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[mi], racc[mi & 1], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed before anyone reads it
     __syncthreads();
@@ -204,6 +216,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
       *reinterpret_cast<float4 *>(cs + row * 64 + ((c4 ^ (row & 15)) << 2)) = v;
     }
   const int64_t mw = m0 + wm * 64, nw = n0 + wn * 64;
+  if (EPI == 1 && do_rowsum && lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t m = mw + (wn * 2 + j) * 16 + lane;
+      if (m < g.M) atomicAdd(g.rowsum + m, racc[j][0] * g.alpha);
+    }
+  }
   if (EPI == 1) {
     float *C = (float *)g.C;
     const int64_t n = nw + lane;
@@ -282,6 +301,7 @@ int check_and_fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = 1;
+  g.rowsum = nullptr;
   return LDM_OK;
 }
 
@@ -307,7 +327,8 @@ int ldm_gemm_mfma_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t
 // C(fp32) += alpha * opA(A) * opB(B), K split over workgroups so that small outputs with a
 // long reduction (weight gradients: K = number of tokens) still fill the chip.
 int ldm_gemm_mfma_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
-                           int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s) {
+                           int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, float *rowsum,
+                           hipStream_t s) {
   MArgs g;
   const int rc = check_and_fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
   if (rc) return rc;
@@ -320,6 +341,7 @@ int ldm_gemm_mfma_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
   g.splits = (int)splits;
+  g.rowsum = rowsum;
   const bool akc = !transA, bkc = transB != 0;
   if (akc && bkc) return launch_mfma<true, true, float, 1>(g, s);
   if (akc && !bkc) return launch_mfma<true, false, float, 1>(g, s);

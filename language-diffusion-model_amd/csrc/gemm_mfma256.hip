@@ -57,6 +57,9 @@ struct MArgs {
   // not exist; K is *dyn_k rounded up to 32 (the caller zero-fills the rounding rows);
   // row_map sends output row m to C row row_map[m]
   const int *dyn_m, *dyn_k, *row_map;
+  // EPI 1 only: rowsum[m] += alpha * sum_k opA[m, k] (the bias gradient when opA is dy^T),
+  // computed by the workgroups of the first tile column with a ones fragment
+  float *rowsum;
 };
 
 __device__ __forceinline__ int swz_kc(int row) { return 3 * ((row >> 2) & 1); }
@@ -214,6 +217,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    // row sums of opA: wave wn of a first-column tile takes fragments mi = RS*wn .. RS*wn + RS-1
+    constexpr int RS = MI / WN_;
+    f4_t racc[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) racc[j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = EPI == 1 && g.rowsum != nullptr && tid.tn == 0;
 
     // half-tile 0 landed for everybody (also: everybody has left the previous epilogue)
     if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
@@ -253,6 +262,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      if (EPI == 1 && do_rowsum) {
+        const bf8_t ones = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          if (mi / RS == wn)
+            racc[mi % RS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[mi], racc[mi % RS], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -278,6 +294,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         }
     }
 
+    if (EPI == 1 && do_rowsum && lane < 16) {
+      // every register of lane l holds the sum for row (l & 15) of the fragment
+#pragma unroll
+      for (int j = 0; j < RS; ++j) {
+        const int64_t m = m0 + wm * (MI * 16) + (wn * RS + j) * 16 + lane;
+        if (m < Mdyn) atomicAdd(g.rowsum + m, racc[j][0] * g.alpha);
+      }
+    }
     // Epilogue through LDS, 16 rows x 64 columns of fp32 (4 KiB, private to the wave) at a
     // time: fragments go in as 16-byte pieces at chunk c4 ^ row, rows come out contiguous.
     float *cs = reinterpret_cast<float *>(smem + STAGE_OFF + wave * 4096);
@@ -387,6 +411,7 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.splits = 1;
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
+  g.rowsum = nullptr;
   return LDM_OK;
 }
 
@@ -444,7 +469,7 @@ int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, 
 
 int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                                    const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
-                                   const int *dyn_k, hipStream_t s) {
+                                   const int *dyn_k, float *rowsum, hipStream_t s) {
   MArgs g;
   const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
   if (rc) return rc;
@@ -454,12 +479,14 @@ int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N,
   g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
   if ((int64_t)g.tiles_m * g.tiles_n < 200) return LDM_E_SHAPE;   // no K split with a device-side K
   g.dyn_k = dyn_k;
+  g.rowsum = rowsum;
   const bool akc = !transA, bkc = transB != 0;
   return use128 ? dispatch_layout<128, float, 1>(g, akc, bkc, s) : dispatch_layout<256, float, 1>(g, akc, bkc, s);
 }
 
 int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
-                              int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, hipStream_t s) {
+                              int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, float *rowsum,
+                              hipStream_t s) {
   MArgs g;
   const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
   if (rc) return rc;
@@ -470,15 +497,18 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
   const int64_t ntiles = tm * tn;
   if (ntiles > 0x3fffffff) return LDM_E_SHAPE;
   const int64_t np_total = K / KH;
-  // Small outputs with a long reduction go to the 128x128 kernel: filling 256 CUs with
-  // 256x256 tiles would need so many K splits that the float-atomic epilogue
-  // (~1.3 TB/s chip-wide) costs more than the product itself.
+  // Small outputs go to the 128x128 kernel: filling 256 CUs with 256x256 tiles needs so many
+  // K splits that the float-atomic epilogue (~1.3 TB/s chip-wide) costs more than it saves.
   static const bool force = getenv("LDM_GEMM_TILE") && atoi(getenv("LDM_GEMM_TILE")) == 256;
-  if (ntiles < 200 && !force) return LDM_E_SHAPE;
   int64_t splits = ntiles >= 200 ? 1 : 256 / ntiles;
   if (splits > np_total / 8) splits = np_total / 8;              // >= 8 half-tiles per workgroup
   if (splits < 1) splits = 1;
+  // measured crossover: with >= 20 tiles and >= 100 half-tiles per work item the persistent
+  // 256-row kernel wins (861 vs 625 TFLOP/s at 2304x768x65536); below that the atomics dominate
+  const bool worth = ntiles >= 200 || (ntiles >= 20 && np_total / splits >= 100);
+  if (!worth && !force) return LDM_E_SHAPE;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = (int)splits;
+  g.rowsum = rowsum;
   const bool akc = !transA, bkc = transB != 0;
   return use128 ? dispatch_layout<128, float, 1>(g, akc, bkc, s) : dispatch_layout<256, float, 1>(g, akc, bkc, s);
 }

@@ -60,7 +60,8 @@ SIGNATURES = {
     "ldm_gather_rows": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
     "ldm_gemm_rows_dyn": (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                  _vp]),
-    "ldm_gemm_acc_kdyn": (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "ldm_gemm_acc_kdyn": (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "ldm_gemm_acc_rowsum": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "ldm_colsum_rows_dyn": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "ldm_softmax_rows_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ldm_softmax_bwd_rows_f32": (_i32, [_vp, _vp, _i64, _i64, _vp]),

@@ -28,6 +28,7 @@ _ZERO_PADDED: dict[int, int] = {}
 _COMPACT_OK: set[int] = set()
 _COMPACT_GRAD: dict[int, tuple] = {}
 COMPACT_HEAD = True   # set False to force the dense LM-head backward
+FUSED_BIAS_GRAD = True  # bias gradient from the weight-gradient GEMM (False: separate column-sum kernel)
 COMPACT_STATS = {"used": 0}
 
 
@@ -172,13 +173,21 @@ class _PackedLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, k, dtype=dt, device=g.device)
             _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag=pack.name + ".dx")
-        dw = torch.zeros(n_pad, k, dtype=torch.float32, device=g.device)
-        N.check(N.lib().ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad,
-                                     x2.data_ptr(), x2.stride(0), dw.data_ptr(), k, N.stream()), "ldm_gemm_acc")
-        db = torch.empty(n_pad, dtype=torch.float32, device=g.device)
-        ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
-        N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
-                                   ws.data_ptr(), N.stream()), "ldm_colsum")
+        # dW and db share one zeroed buffer ([n_pad, k] then [n_pad]) and, for bf16, one kernel
+        dwb = torch.zeros(n_pad * k + n_pad, dtype=torch.float32, device=g.device)
+        dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
+        rc = -2
+        if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
+            rc = N.lib().ldm_gemm_acc_rowsum(1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad, x2.data_ptr(),
+                                             x2.stride(0), dw.data_ptr(), k, db.data_ptr(), N.stream())
+            if rc not in (-2, -3):
+                N.check(rc, "ldm_gemm_acc_rowsum")
+        if rc in (-2, -3):
+            N.check(N.lib().ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad,
+                                         x2.data_ptr(), x2.stride(0), dw.data_ptr(), k, N.stream()), "ldm_gemm_acc")
+            ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
+            N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
+                                       ws.data_ptr(), N.stream()), "ldm_colsum")
         grads_w, grads_b = [], []
         off = 0
         for ne in pack.n_each:
@@ -209,16 +218,17 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
     xc = torch.empty(Tp, k, dtype=torch.bfloat16, device=dev)
     N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), count.data_ptr(), T, k,
                                 xc.data_ptr(), st), "ldm_gather_rows")
-    dw = torch.zeros(n_pad, k, dtype=torch.float32, device=dev)
+    dwb = torch.zeros(n_pad * k + n_pad, dtype=torch.float32, device=dev)
+    dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
     rc = lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, Tp, dlc.data_ptr(), n_pad, xc.data_ptr(), k, dw.data_ptr(), k,
-                               count.data_ptr(), st)
+                               count.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None, st)
     if rc in (-2, -3):
         return None
     N.check(rc, "ldm_gemm_acc_kdyn")
-    db = torch.empty(n_pad, dtype=torch.float32, device=dev)
-    ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
-    N.check(lib.ldm_colsum_rows_dyn(dlc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
-                                    count.data_ptr(), st), "ldm_colsum_rows_dyn")
+    if not FUSED_BIAS_GRAD:
+        ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
+        N.check(lib.ldm_colsum_rows_dyn(dlc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
+                                        count.data_ptr(), st), "ldm_colsum_rows_dyn")
     grads_w, grads_b = [], []
     off = 0
     for ne in pack.n_each:
@@ -612,13 +622,15 @@ class _HeadMaskedCE(torch.autograd.Function):
             dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
             N.check(lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, lc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(),
                                           k, None, cnt.data_ptr(), rows.data_ptr(), st), "ldm_gemm_rows_dyn")
-        dw = torch.zeros(n_pad, k, dtype=torch.float32, device=dev)
+        dwb = torch.zeros(n_pad * k + n_pad, dtype=torch.float32, device=dev)
+        dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
         N.check(lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, _round_up(T, 64), lc.data_ptr(), n_pad, xc.data_ptr(), k,
-                                      dw.data_ptr(), k, cnt.data_ptr(), st), "ldm_gemm_acc_kdyn")
-        db = torch.empty(n_pad, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
-        N.check(lib.ldm_colsum_rows_dyn(lc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
-                                        cnt.data_ptr(), st), "ldm_colsum_rows_dyn")
+                                      dw.data_ptr(), k, cnt.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None,
+                                      st), "ldm_gemm_acc_kdyn")
+        if not FUSED_BIAS_GRAD:
+            ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
+            N.check(lib.ldm_colsum_rows_dyn(lc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
+                                            cnt.data_ptr(), st), "ldm_colsum_rows_dyn")
         grads_w, grads_b = [], []
         off = 0
         for ne in pack.n_each:

@@ -263,6 +263,26 @@ def test_gemm_acc_split_k(dev, ta, tb, M, N, K):
     assert rel_err(c, c0.double() + A @ Bm) < 1e-5
 
 
+@pytest.mark.parametrize("ta,tb", [(1, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 4096), (2304, 768, 32768), (2048, 768, 65536), (30528, 768, 2048),
+                                   (200, 136, 640)])
+def test_gemm_acc_rowsum(dev, ta, tb, M, N, K):
+    """C += A*B and rowsum += row sums of op(A) from one kernel (weight + bias gradient)."""
+    from src import _native as Nn
+    torch.manual_seed(4)
+    a = torch.randn((K, M) if ta else (M, K), device=dev).bfloat16()
+    b = torch.randn((N, K) if tb else (K, N), device=dev).bfloat16()
+    c0 = torch.randn(M, N, device=dev)
+    r0 = torch.randn(M, device=dev)
+    c, r = c0.clone(), r0.clone()
+    Nn.check(Nn.lib().ldm_gemm_acc_rowsum(ta, tb, M, N, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                          c.data_ptr(), N, r.data_ptr(), Nn.stream()), "ldm_gemm_acc_rowsum")
+    A = a.double().t() if ta else a.double()
+    Bm = b.double().t() if tb else b.double()
+    assert rel_err(c, c0.double() + A @ Bm) < 1e-5
+    assert rel_err(r, r0.double() + A.sum(dim=1)) < 1e-5
+
+
 def test_gemm_bf16_fallback_shapes(dev):
     """Shapes the MFMA kernel does not take (K % 64 != 0) run on the FMA kernel."""
     torch.manual_seed(2)
