@@ -60,6 +60,7 @@ struct MArgs {
   // EPI 1 only: rowsum[m] += alpha * sum_k opA[m, k] (the bias gradient when opA is dy^T),
   // computed by the workgroups of the first tile column with a ones fragment
   float *rowsum;
+  int dbg;   // timing experiments only (LDM_GEMM_DBG): 1 no stagger, 2 no LDS-DMA in the loop, 4 no LDS reads
 };
 
 __device__ __forceinline__ int swz_kc(int row) { return 3 * ((row >> 2) & 1); }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
-  const bool late = wave >= 4;
+  const bool late = wave >= 4 && !(g.dbg & 1);
 
   const int64_t Mdyn = g.dyn_m ? (int64_t)*g.dyn_m : g.M;
   // with a device-side row count only the m-tiles that hold rows are walked
@@ -192,24 +193,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
     }
 
+  // stores per wave in the fast-path epilogue (16 bytes per lane each)
+  constexpr int NST = MI * (sizeof(TO) == 2 ? 2 : 4);
+  static_assert(2 * P + NST <= 63, "vmcnt is a 6-bit counter");
+  bool carry_next = false;
+  const unsigned stage_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + STAGE_OFF + wave * 4096;
+
   while (true) {
     const int64_t m0 = (int64_t)tid.tm * BM, n0 = (int64_t)tid.tn * BN;
     const int64_t nw = n0 + wn * 64;
-    // bias of this lane's 4 output columns; the empty asm is a use, so the compiler's wait for
+    // Output columns of a lane in the store phase of the epilogue: CPL consecutive ones
+    // (16 bytes of TO), so a row of the wave's 64 columns is written by 64 / CPL lanes.
+    constexpr int CPL = sizeof(TO) == 2 ? 8 : 4;
+    constexpr int LPR = 64 / CPL;         // lanes per row
+    constexpr int RPP = 64 / LPR;         // rows per store instruction
+    // bias of this lane's output columns; the empty asm is a use, so the compiler's wait for
     // the load sits HERE (it drains the three half-tiles in flight, which are needed next
     // anyway) and not inside the epilogue, where it would drain the next item's prefetch.
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    float bv[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) bv[j] = 0.f;
     if (EPI == 0 && g.bias) {
-      const int64_t n = nw + (lane & 15) * 4;
-      if (n + 3 < g.N) {
-        const float4 t = *reinterpret_cast<const float4 *>(g.bias + n);
-        b0 = t.x; b1 = t.y; b2 = t.z; b3 = t.w;
-      } else {
-        if (n < g.N) b0 = g.bias[n];
-        if (n + 1 < g.N) b1 = g.bias[n + 1];
-        if (n + 2 < g.N) b2 = g.bias[n + 2];
-      }
-      asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+      const int64_t n = nw + (lane % LPR) * CPL;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+        if (n + j < g.N) bv[j] = g.bias[n + j];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) asm volatile("" : "+v"(bv[j]));
     }
 
     f4_t acc[NI][MI];
@@ -224,8 +234,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     for (int j = 0; j < RS; ++j) racc[j] = f4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = EPI == 1 && g.rowsum != nullptr && tid.tn == 0;
 
-    // half-tile 0 landed for everybody (also: everybody has left the previous epilogue)
-    if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    // half-tile 0 landed for everybody (also: everybody has left the previous epilogue).
+    // After a fast-path epilogue exactly NST stores of this wave are YOUNGER than the three
+    // half-tiles prefetched before it (vmcnt counts loads and stores together, in issue
+    // order): counting them in lets the first two phases start while those stores drain.
+    const bool carry = carry_next && np > 3;
+    carry_next = false;
+    if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NST) : "memory");
+    else if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
     else if (np > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -238,18 +254,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
 
     for (int p = 0; p < np; ++p) {
       // ---- segment R: retire this wave's pieces of half-tile p+1, read p, refill the slot of p-1
-      if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-      else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(g.dbg & 32)) {   // 32: no counted wait (results invalid; timing only)
+        if (carry && p < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NST) : "memory");
+        else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+        else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       const char *cur = smem + (p & 3) * HT;
       bf8_t fa[MI], fb[NI];
+      if (!(g.dbg & 4) || p == 0) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) fb[i] = read_frag<B_KC, BN>(cur + HT_A, wn * 64 + i * 16, lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_KC, BM>(cur, wm * (MI * 16) + i * 16, lane);
-      if (p + 3 < np) {
+      }
+      if (p + 3 < np && !(g.dbg & 2)) {
         char *slot = smem + ((p + 3) & 3) * HT;
-        stage_issue<PA>(srcA, (int64_t)(p_begin + p + 3) * kstepA, slot, wave);
-        stage_issue<PB>(srcB, (int64_t)(p_begin + p + 3) * kstepB, slot + HT_A, wave);
+        const int pk = (g.dbg & 16) ? 0 : p + 3;   // 16: every loop load re-reads half-tile 0 (cache-hot source)
+        stage_issue<PA>(srcA, (int64_t)(p_begin + pk) * kstepA, slot, wave);
+        stage_issue<PB>(srcB, (int64_t)(p_begin + pk) * kstepB, slot + HT_A, wave);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of half-tile p are complete
       __builtin_amdgcn_sched_barrier(0);
@@ -302,6 +324,53 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         if (m < Mdyn) atomicAdd(g.rowsum + m, racc[j][0] * g.alpha);
       }
     }
+    // Fast-path epilogue (tile fully inside C, no residual, no row map, 16-byte-aligned rows):
+    // the same LDS re-shaping as below, but with the LDS accesses written as asm so that the
+    // compiler does not order them behind the LDS-DMA prefetch just issued (it would drain it
+    // with vmcnt(0): it cannot see that the staging area and the ring are disjoint), and with a
+    // fixed number of unconditional 16-byte stores (NST), which the next item's waits count on.
+    if (EPI == 0 && !g.R && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0 &&
+        !(g.dbg & 8)) {
+      TO *C = (TO *)g.C;
+      const int cl = lane % LPR;
+      const int wrow = lane & 15;
+      const unsigned waddr = stage_lds + wrow * 256;
+      TO *crow = C + (m0 + wm * (MI * 16) + lane / LPR) * g.ldc + nw + cl * CPL;
+      const int64_t rstep = (int64_t)RPP * g.ldc;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int c4 = ni * 4 + (lane >> 4);
+          f4_t a = acc[ni][mi] * g.alpha;
+          asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + ((c4 ^ wrow) << 4)), "v"(a) : "memory");
+        }
+#pragma unroll
+        for (int it = 0; it < 16 / RPP; ++it) {
+          const int row = it * RPP + lane / LPR;
+          f4_t t[CPL / 4];
+#pragma unroll
+          for (int q = 0; q < CPL / 4; ++q) {
+            const int c4 = cl * (CPL / 4) + q;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t[q]) : "v"(stage_lds + row * 256 + ((c4 ^ row) << 4)) : "memory");
+          }
+          if (CPL == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[CPL / 4 - 1])::"memory");
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = t[j / 4][j % 4] + bv[j % CPL];
+            Raw8<TO>::store(crow, o);
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0])::"memory");
+            st4(crow, f4{{t[0][0] + bv[0], t[0][1] + bv[1], t[0][2] + bv[2], t[0][3] + bv[3]}});
+          }
+          crow += rstep;
+        }
+      }
+      carry_next = more;
+      if (!more) break;
+      continue;
+    }
     // Epilogue through LDS, 16 rows x 64 columns of fp32 (4 KiB, private to the wave) at a
     // time: fragments go in as 16-byte pieces at chunk c4 ^ row, rows come out contiguous.
     float *cs = reinterpret_cast<float *>(smem + STAGE_OFF + wave * 4096);
@@ -327,29 +396,51 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       } else {
         TO *C = (TO *)g.C;
         const TO *R = (const TO *)g.R;
-        const bool vec_ok = (g.ldc % 4 == 0) && (!R || g.ldr % 4 == 0);
-        const int c4 = lane & 15;
-        const int64_t n = nw + c4 * 4;
+        const bool vec_ok = (g.ldc % CPL == 0) && (!R || g.ldr % CPL == 0);
+        const int cl = lane % LPR;                 // this lane's column group
+        const int64_t n = nw + cl * CPL;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = it * 4 + (lane >> 4);
-          const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ row) << 2));
+        for (int it = 0; it < 16 / RPP; ++it) {
+          const int row = it * RPP + lane / LPR;
+          float v[CPL];
+#pragma unroll
+          for (int q = 0; q < CPL / 4; ++q) {
+            const int c4 = cl * (CPL / 4) + q;
+            const float4 t = *reinterpret_cast<const float4 *>(cs + row * 64 + ((c4 ^ row) << 2));
+            v[q * 4 + 0] = t.x + bv[q * 4 + 0];
+            v[q * 4 + 1] = t.y + bv[q * 4 + 1];
+            v[q * 4 + 2] = t.z + bv[q * 4 + 2];
+            v[q * 4 + 3] = t.w + bv[q * 4 + 3];
+          }
           int64_t m = mw + row;
-          if (m >= Mdyn || n >= g.N) continue;
+          if (m >= Mdyn || n >= g.N || (g.dbg & 8)) continue;
           if (g.row_map) m = g.row_map[m];
-          f4 v{{t.x + b0, t.y + b1, t.z + b2, t.w + b3}};
-          if (n + 3 < g.N && vec_ok) {
-            if (R) {
-              const f4 r = ld4(R + m * g.ldr + n);
+          if (n + CPL - 1 < g.N && vec_ok) {
+            if (CPL == 8) {
+              if (R) {
+                Raw8<TO> r;
+                r.load(R + m * g.ldr + n);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v.v[j] += r.v[j];
+                for (int j = 0; j < 8; ++j) v[j] += r.get(j);
+              }
+              float o[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = v[j % CPL];
+              Raw8<TO>::store(C + m * g.ldc + n, o);
+            } else {
+              f4 o{{v[0], v[1], v[2], v[3]}};
+              if (R) {
+                const f4 r = ld4(R + m * g.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o.v[j] += r.v[j];
+              }
+              st4(C + m * g.ldc + n, o);
             }
-            st4(C + m * g.ldc + n, v);
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < CPL; ++j)
               if (n + j < g.N) {
-                float x = v.v[j];
+                float x = v[j];
                 if (R) x += Elt<TO>::ld(R + m * g.ldr + n + j);
                 Elt<TO>::st(C + m * g.ldc + n + j, x);
               }
@@ -412,6 +503,8 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.splits = 1;
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
   g.rowsum = nullptr;
+  static const int dbg = getenv("LDM_GEMM_DBG") ? atoi(getenv("LDM_GEMM_DBG")) : 0;
+  g.dbg = dbg;
   return LDM_OK;
 }
 
