@@ -60,8 +60,17 @@ struct MArgs {
   // EPI 1 only: rowsum[m] += alpha * sum_k opA[m, k] (the bias gradient when opA is dy^T),
   // computed by the workgroups of the first tile column with a ones fragment
   float *rowsum;
-  int dbg;   // timing experiments only (LDM_GEMM_DBG): 1 no stagger, 2 no LDS-DMA in the loop, 4 no LDS reads
+  unsigned long long *timing;   // experiment builds: segment cycle totals [8 waves][8]
 };
+
+// Experiment builds (-DLDM_GEMM_TIMING): cycle totals of the main-loop segments of workgroup 17
+// are written to the device address given in the environment variable LDM_GEMM_TIMING_BUF.
+#ifdef LDM_GEMM_TIMING
+#define TSTAMP(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); \
+                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define TSTAMP(var) do { } while (0)
+#endif
 
 __device__ __forceinline__ int swz_kc(int row) { return 3 * ((row >> 2) & 1); }
 __device__ __forceinline__ int swz_st(int kr) { return ((kr & 3) | (((kr >> 3) & 1) << 2)) << 1; }
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
-  const bool late = wave >= 4 && !(g.dbg & 1);
+  const bool late = wave >= 4;
 
   const int64_t Mdyn = g.dyn_m ? (int64_t)*g.dyn_m : g.M;
   // with a device-side row count only the m-tiles that hold rows are walked
@@ -196,6 +205,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   // stores per wave in the fast-path epilogue (16 bytes per lane each)
   constexpr int NST = MI * (sizeof(TO) == 2 ? 2 : 4);
   static_assert(2 * P + NST <= 63, "vmcnt is a 6-bit counter");
+#ifdef LDM_GEMM_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long te0 = 0, te1 = 0;
+#endif
   bool carry_next = false;
   const unsigned stage_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + STAGE_OFF + wave * 4096;
 
@@ -238,6 +251,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // After a fast-path epilogue exactly NST stores of this wave are YOUNGER than the three
     // half-tiles prefetched before it (vmcnt counts loads and stores together, in issue
     // order): counting them in lets the first two phases start while those stores drain.
+    TSTAMP(te1);
+#ifdef LDM_GEMM_TIMING
+    if (te0) tacc[6] += te1 - te0;   // previous item's epilogue (+ next item's set-up and prefetch issue)
+#endif
     const bool carry = carry_next && np > 3;
     carry_next = false;
     if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NST) : "memory");
@@ -251,32 +268,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // LDS-DMA.  The second half takes one extra barrier here and the first half one after
     // the loop, so every s_barrier below pairs segment R of one half with segment M of the other.
     if (late) __builtin_amdgcn_s_barrier();
+#ifdef LDM_GEMM_TIMING
+    { unsigned long long tp; TSTAMP(tp); tacc[7] += tp - te1; }   // wait for the first half-tile + barriers
+#endif
 
+#ifdef LDM_GEMM_TIMING
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+#endif
     for (int p = 0; p < np; ++p) {
+      TSTAMP(t0);
       // ---- segment R: retire this wave's pieces of half-tile p+1, read p, refill the slot of p-1
-      if (!(g.dbg & 32)) {   // 32: no counted wait (results invalid; timing only)
-        if (carry && p < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NST) : "memory");
-        else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-        else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (carry && p < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NST) : "memory");
+      else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+      else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TSTAMP(t1);
       const char *cur = smem + (p & 3) * HT;
       bf8_t fa[MI], fb[NI];
-      if (!(g.dbg & 4) || p == 0) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) fb[i] = read_frag<B_KC, BN>(cur + HT_A, wn * 64 + i * 16, lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_KC, BM>(cur, wm * (MI * 16) + i * 16, lane);
-      }
-      if (p + 3 < np && !(g.dbg & 2)) {
+      if (p + 3 < np) {
         char *slot = smem + ((p + 3) & 3) * HT;
-        const int pk = (g.dbg & 16) ? 0 : p + 3;   // 16: every loop load re-reads half-tile 0 (cache-hot source)
-        stage_issue<PA>(srcA, (int64_t)(p_begin + pk) * kstepA, slot, wave);
-        stage_issue<PB>(srcB, (int64_t)(p_begin + pk) * kstepB, slot + HT_A, wave);
+        stage_issue<PA>(srcA, (int64_t)(p_begin + p + 3) * kstepA, slot, wave);
+        stage_issue<PB>(srcB, (int64_t)(p_begin + p + 3) * kstepB, slot + HT_A, wave);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of half-tile p are complete
+      TSTAMP(t2);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      TSTAMP(t3);
       // ---- segment M
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -292,11 +314,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
             racc[mi % RS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[mi], racc[mi % RS], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
+      TSTAMP(t4);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+#ifdef LDM_GEMM_TIMING
+      TSTAMP(t5);
+      tacc[0] += t1 - t0;   // counted vmcnt wait
+      tacc[1] += t2 - t1;   // LDS reads + LDS-DMA issue + lgkmcnt(0)
+      tacc[2] += t3 - t2;   // barrier after R
+      tacc[3] += t4 - t3;   // MFMA issue
+      tacc[4] += t5 - t4;   // barrier after M
+      tacc[5] += 1;         // phases
+#endif
     }
     if (!late) __builtin_amdgcn_s_barrier();
+    TSTAMP(te0);
     // All reads of the ring are complete for every wave (lgkmcnt(0) before each barrier) and
     // no LDS-DMA is outstanding: slots 0-2 can take the next item's first half-tiles now.
 
@@ -329,8 +362,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // compiler does not order them behind the LDS-DMA prefetch just issued (it would drain it
     // with vmcnt(0): it cannot see that the staging area and the ring are disjoint), and with a
     // fixed number of unconditional 16-byte stores (NST), which the next item's waits count on.
-    if (EPI == 0 && !g.R && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0 &&
-        !(g.dbg & 8)) {
+    if (EPI == 0 && !g.R && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0) {
       TO *C = (TO *)g.C;
       const int cl = lane % LPR;
       const int wrow = lane & 15;
@@ -368,6 +400,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         }
       }
       carry_next = more;
+#ifdef LDM_GEMM_TIMING
+      if (!more && g.timing && lane == 0 && blockIdx.x == 17)
+        for (int i = 0; i < 8; ++i) g.timing[wave * 8 + i] = tacc[i];
+#endif
       if (!more) break;
       continue;
     }
@@ -413,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
             v[q * 4 + 3] = t.w + bv[q * 4 + 3];
           }
           int64_t m = mw + row;
-          if (m >= Mdyn || n >= g.N || (g.dbg & 8)) continue;
+          if (m >= Mdyn || n >= g.N) continue;
           if (g.row_map) m = g.row_map[m];
           if (n + CPL - 1 < g.N && vec_ok) {
             if (CPL == 8) {
@@ -448,6 +484,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         }
       }
     }
+#ifdef LDM_GEMM_TIMING
+      if (!more && g.timing && lane == 0 && blockIdx.x == 17)
+        for (int i = 0; i < 8; ++i) g.timing[wave * 8 + i] = tacc[i];
+#endif
     if (!more) break;
   }
 }
@@ -503,8 +543,8 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.splits = 1;
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
   g.rowsum = nullptr;
-  static const int dbg = getenv("LDM_GEMM_DBG") ? atoi(getenv("LDM_GEMM_DBG")) : 0;
-  g.dbg = dbg;
+  static const char *tb = getenv("LDM_GEMM_TIMING_BUF");
+  g.timing = tb ? (unsigned long long *)strtoull(tb, nullptr, 0) : nullptr;
   return LDM_OK;
 }
 

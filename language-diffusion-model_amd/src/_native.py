@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
+LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
