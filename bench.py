@@ -183,6 +183,15 @@ def main():
         d_, V_ = cfg["d_model"], cfg["vocab_size"]
         # work actually executed: the three LM-head GEMMs run on the participating rows only
         fpt_exec = fpt - 6.0 * d_ * V_ * (1.0 - head_rows)
+        # memory-side bytes of that kernel per launch, from the committed PMC passes (per-row rates
+        # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled to this run's row count)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_head_fwd_traffic.json")
+        if os.path.exists(tpath) and args.config == "default" and args.dtype == "bf16":
+            tj = json.load(open(tpath))
+            rows_m = sum(l["rows"] for l in tj["launches"])
+            per_row = sum(l["fetch_kib_raw"] * tj["fetch_correction"] + l["write_kib"] for l in tj["launches"]) * 1024.0 / rows_m
+            traffic = per_row * head_rows * args.batch * args.seq
         out = {
             "metric": "masked-diffusion train tokens/sec (node)", "value": tps, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,7 +208,7 @@ def main():
             "executed_flops_per_token": fpt_exec, "lm_head_rows_fraction": head_rows,
             "roofline": {"kernel": "gemm256_k (LM-head forward GEMM over the rows the loss reads)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "flops_per_launch": flops, "avg_launch_ms": avg_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
