@@ -204,6 +204,9 @@ def main():
                        **cfg},
             "loss_last_step": last,
             "train_flops_per_token": fpt,
+            # fraction of the bf16 MFMA peak: with the flops of the reference's step (LM head on every
+            # position) and with the flops executed here (LM head on the rows the loss reads)
+            "mfma_fraction_algorithmic": tps * fpt / (world * PEAK_BF16_TFLOPS * 1e12),
             "mfma_fraction_of_step": tps * fpt_exec / (world * PEAK_BF16_TFLOPS * 1e12),
             "executed_flops_per_token": fpt_exec, "lm_head_rows_fraction": head_rows,
             "roofline": {"kernel": "gemm256_k (LM-head forward GEMM over the rows the loss reads)", "bound": "mfma",
