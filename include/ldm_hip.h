@@ -166,6 +166,15 @@ int ldm_attn_bwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_
                  int64_t batch, int64_t nhead, int64_t seq, int64_t hd, const void *o,
                  const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
                  void *stream);
+/* ldm_attn_bwd followed by the backward of ldm_rope_qk in one pass: dq and dk are written as the
+ * gradients w.r.t. the q and k BEFORE apply_rotary_pos_emb and the query scale
+ * (src/transformer.py:178-185, 255-258 under autograd), i.e. exactly what
+ * ldm_attn_bwd + ldm_rope_qk(inverse = 1, q_scale) leave in dqkv.  cos_t / sin_t: fp32 [seq, hd/2].
+ * BF16 with hd in {32, 64, 96, 128} only; otherwise LDM_E_SHAPE (use the two calls). */
+int ldm_attn_bwd_unrope(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                        int64_t batch, int64_t nhead, int64_t seq, int64_t hd, const void *o,
+                        const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
+                        const float *cos_t, const float *sin_t, float q_scale, void *stream);
 
 /* ---------------------------------------------------------------- K4: masked cross-entropy
  * masked_cross_entropy_loss / variational_lower_bound_loss (src/loss.py:8-65).

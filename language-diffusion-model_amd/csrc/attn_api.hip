@@ -29,9 +29,10 @@ extern "C" int ldm_attn_fwd(int dtype, const void *qkv, int64_t ld_qkv, const ui
   return LDM_E_DTYPE;
 }
 
-extern "C" int ldm_attn_bwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,
-                            int64_t nhead, int64_t seq, int64_t hd, const void *o, const void *do_, int64_t ld_o,
-                            const void *saved, void *dqkv, void *ws, void *stream) {
+static int attn_bwd_impl(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,
+                         int64_t nhead, int64_t seq, int64_t hd, const void *o, const void *do_, int64_t ld_o,
+                         const void *saved, void *dqkv, void *ws, const float *rope_cos, const float *rope_sin,
+                         float rope_scale, void *stream) {
   if (batch < 0 || nhead <= 0 || seq < 0 || hd <= 0) return LDM_E_BADARG;
   if (batch == 0 || seq == 0) return LDM_OK;
   if (!qkv || !o || !do_ || !saved || !dqkv || !ws) return LDM_E_BADARG;
@@ -39,9 +40,27 @@ extern "C" int ldm_attn_bwd(int dtype, const void *qkv, int64_t ld_qkv, const ui
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LDM_BF16)
     return ldm_flash_bwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (const bf16_t *)o,
-                              (const bf16_t *)do_, ld_o, (const float *)saved, (bf16_t *)dqkv, (float *)ws, s);
+                              (const bf16_t *)do_, ld_o, (const float *)saved, (bf16_t *)dqkv, (float *)ws, rope_cos,
+                              rope_sin, rope_scale, s);
+  if (rope_cos) return LDM_E_SHAPE;
   if (dtype == LDM_F32)
     return ldm_attn_bwd_f32((const float *)qkv, ld_qkv, batch, nhead, seq, hd, (const float *)do_, ld_o,
                             (const float *)saved, (float *)dqkv, (float *)ws, s);
   return LDM_E_DTYPE;
+}
+
+extern "C" int ldm_attn_bwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,
+                            int64_t nhead, int64_t seq, int64_t hd, const void *o, const void *do_, int64_t ld_o,
+                            const void *saved, void *dqkv, void *ws, void *stream) {
+  return attn_bwd_impl(dtype, qkv, ld_qkv, key_valid, batch, nhead, seq, hd, o, do_, ld_o, saved, dqkv, ws, nullptr,
+                       nullptr, 1.0f, stream);
+}
+
+extern "C" int ldm_attn_bwd_unrope(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                                   int64_t batch, int64_t nhead, int64_t seq, int64_t hd, const void *o,
+                                   const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
+                                   const float *cos_t, const float *sin_t, float q_scale, void *stream) {
+  if (!cos_t || !sin_t) return LDM_E_BADARG;
+  return attn_bwd_impl(dtype, qkv, ld_qkv, key_valid, batch, nhead, seq, hd, o, do_, ld_o, saved, dqkv, ws, cos_t,
+                       sin_t, q_scale, stream);
 }

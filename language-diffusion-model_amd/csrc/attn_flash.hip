@@ -44,6 +44,9 @@ struct FArgs {
   bf16_t *o; const bf16_t *o_in; const bf16_t *dout; int64_t ld_o;
   float *lse; const float *lse_in;
   bf16_t *dqkv; float *delta;
+  // optional (backward): fp32 [S, hd/2] rotary tables; dq and dk are then written as gradients
+  // w.r.t. the PRE-rotation q and k (dq also multiplied by rope_scale, the factor q was scaled by)
+  const float *rope_cos, *rope_sin; float rope_scale;
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -122,6 +125,34 @@ __device__ __forceinline__ void store_rows(bf16_t *dst_row, const f16_t (&acc)[A
         st4(dst_row + d, v);
       }
     }
+}
+
+// store_rows with the transposed rotary rotation applied first (head dim == DP): the pair
+// (d, d + DP/2) of one row lives in ONE lane -- registers of block d/32 and of block
+// (d + DP/2)/32 -- so the rotation needs no exchange.  Forward (src/transformer.py:178-185):
+// y[d] = x[d] cos - x[d+h] sin, y[d+h] = x[d+h] cos + x[d] sin; this applies the transpose.
+template <int DP>
+__device__ __forceinline__ void store_rows_unrope(bf16_t *dst_row, const f16_t (&acc)[AT<DP>::ND], float scale,
+                                                  int half, const float *cos_row, const float *sin_row) {
+  constexpr int H2 = DP / 2;
+#pragma unroll
+  for (int d0 = 0; d0 < H2; d0 += 8) {
+    constexpr int dummy = 0; (void)dummy;
+    const int lb = d0 / 32, lr = (d0 % 32) / 8;
+    const int e0 = d0 + H2;
+    const int hb = e0 / 32, hr = (e0 % 32) / 8;
+    const int d = d0 + 4 * half;
+    const f4 cs = ld4(cos_row + d), sn = ld4(sin_row + d);
+    f4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gl = acc[lb][4 * lr + j], gh = acc[hb][4 * hr + j];
+      lo.v[j] = (gl * cs.v[j] + gh * sn.v[j]) * scale;
+      hi.v[j] = (gh * cs.v[j] - gl * sn.v[j]) * scale;
+    }
+    st4(dst_row + d, lo);
+    st4(dst_row + d + H2, hi);
+  }
 }
 
 // --------------------------------------------------------------------------- forward
@@ -332,7 +363,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
       __syncthreads();
     }
   }
-  if (q < S) store_rows<DP>(a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd, dq, 1.0f, half, hd);
+  if (q < S) {
+    bf16_t *row = a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd;
+    if (a.rope_cos) store_rows_unrope<DP>(row, dq, a.rope_scale, half, a.rope_cos + (int64_t)q * (DP / 2), a.rope_sin + (int64_t)q * (DP / 2));
+    else store_rows<DP>(row, dq, 1.0f, half, hd);
+  }
 }
 
 // --------------------------------------------------------------------------- dK, dV
@@ -444,7 +479,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
   }
   if (key < S) {
     bf16_t *row = a.dqkv + ((int64_t)b * S + key) * a.ld + (int64_t)head * hd;
-    store_rows<DP>(row + D, dk, 1.0f, half, hd);
+    if (a.rope_cos) store_rows_unrope<DP>(row + D, dk, 1.0f, half, a.rope_cos + (int64_t)key * (DP / 2), a.rope_sin + (int64_t)key * (DP / 2));
+    else store_rows<DP>(row + D, dk, 1.0f, half, hd);
     store_rows<DP>(row + 2 * D, dv, 1.0f, half, hd);
   }
 }
@@ -494,8 +530,14 @@ int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
 
 int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
                        int64_t hd, const bf16_t *o, const bf16_t *dout, int64_t ld_o, const float *lse,
-                       bf16_t *dqkv, float *delta, hipStream_t s) {
+                       bf16_t *dqkv, float *delta, const float *rope_cos, const float *rope_sin, float rope_scale,
+                       hipStream_t s) {
   FArgs a{};
+  if (rope_cos) {   // fused un-rotation: head dim must fill its template and the tables must be 16-byte aligned
+    if (!rope_sin || !(hd == 32 || hd == 64 || hd == 96 || hd == 128)) return LDM_E_SHAPE;
+    if (!aligned_to(rope_cos, 16) || !aligned_to(rope_sin, 16)) return LDM_E_ALIGN;
+  }
+  a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_scale = rope_scale;
   a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
   a.o_in = o; a.dout = dout; a.ld_o = ld_o; a.lse_in = lse; a.dqkv = dqkv; a.delta = delta;
   int rc = check(a);

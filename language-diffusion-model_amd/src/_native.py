@@ -50,6 +50,8 @@ SIGNATURES = {
     "ldm_attn_bwd_ws_bytes": (_i64, [_i32, _i64, _i64, _i64, _i64]),
     "ldm_attn_fwd": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "ldm_attn_bwd": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "ldm_attn_bwd_unrope": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                                   _f32, _vp]),
     "ldm_ce_fwd": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                           _vp, _vp, _vp]),
     "ldm_ce_bwd": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,

@@ -28,6 +28,7 @@ _ZERO_PADDED: dict[int, int] = {}
 _COMPACT_OK: set[int] = set()
 _COMPACT_GRAD: dict[int, tuple] = {}
 COMPACT_HEAD = True   # set False to force the dense LM-head backward
+FUSED_UNROPE = True     # rotary backward inside the attention-backward stores (False: separate pass)
 FUSED_BIAS_GRAD = True  # bias gradient from the weight-gradient GEMM (False: separate column-sum kernel)
 COMPACT_STATS = {"used": 0}
 
@@ -445,11 +446,20 @@ class _RopeAttention(torch.autograd.Function):
         g = g.contiguous()
         dqkv = torch.empty_like(q2)
         ws = torch.empty(lib.ldm_attn_bwd_ws_bytes(code, B, H, S, hd), dtype=torch.uint8, device=q2.device)
-        N.check(lib.ldm_attn_bwd(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
-                                 g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), N.stream()),
-                "ldm_attn_bwd")
-        N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
-                                1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
+        # attention backward with the rotary backward fused into its stores where the kernel has it
+        rc = -3
+        if FUSED_UNROPE and dt == torch.bfloat16:
+            rc = lib.ldm_attn_bwd_unrope(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                         g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
+                                         cos.data_ptr(), sin.data_ptr(), 1.0 / math.sqrt(hd), N.stream())
+            if rc not in (-2, -3):
+                N.check(rc, "ldm_attn_bwd_unrope")
+        if rc in (-2, -3):
+            N.check(lib.ldm_attn_bwd(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                     g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), N.stream()),
+                    "ldm_attn_bwd")
+            N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
+                                    1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
         return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None
 
 

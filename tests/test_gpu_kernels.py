@@ -348,3 +348,27 @@ def test_attention_fwd_bwd(dev, dtype, B, S, H, hd, ragged):
     gq, gr = qkv.grad.float().view(B, S, 3, D), qr.grad.view(B, S, 3, D)
     for i, nm in enumerate("qkv"):
         assert rel_err(gq[:, :, i], gr[:, :, i]) < tol, f"d{nm}"
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(2, 130, 2, 64), (1, 512, 8, 96), (2, 200, 3, 32), (1, 256, 2, 128)])
+def test_attention_bwd_fused_unrope_matches_two_pass(dev, B, S, H, hd):
+    """The rotary backward fused into the attention-backward stores gives what the separate
+    ldm_rope_qk(inverse) pass gives (the fused form rounds to bf16 once instead of twice)."""
+    from src import ops
+    from src.transformer import RotaryPositionEmbedding
+    torch.manual_seed(1)
+    D = H * hd
+    base = (torch.randn(B, S, 3 * D, device=dev) * 1.5).bfloat16()
+    cos, sin = RotaryPositionEmbedding(hd).half_tables(base, S)
+    go = torch.randn(B, S, D, device=dev).bfloat16()
+    grads = {}
+    for fused in (True, False):
+        ops.FUSED_UNROPE = fused
+        try:
+            x = base.clone().requires_grad_(True)
+            ops.rope_attention(x * 1.0, None, B, S, H, hd, cos, sin).backward(go)
+        finally:
+            ops.FUSED_UNROPE = True
+        grads[fused] = x.grad.float()
+    assert rel_err(grads[True], grads[False]) < 6e-3
+    assert torch.equal(grads[True].view(B, S, 3, D)[:, :, 2], grads[False].view(B, S, 3, D)[:, :, 2])   # dv untouched
