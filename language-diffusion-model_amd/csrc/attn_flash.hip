@@ -17,6 +17,7 @@
 // row-major [row][d] LDS tile.
 #include "common.h"
 #include "attn.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,11 +45,22 @@ struct FArgs {
   bf16_t *o; const bf16_t *o_in; const bf16_t *dout; int64_t ld_o;
   float *lse; const float *lse_in;
   bf16_t *dqkv; float *delta;
+  unsigned long long *timing;   // experiment builds only
   // optional (backward): fp32 [S, hd/2] rotary tables; dq and dk are then written as gradients
   // w.r.t. the PRE-rotation q and k (dq also multiplied by rope_scale, the factor q was scaled by)
   const float *rope_cos, *rope_sin; float rope_scale;
 };
 
+// Experiment builds (-DLDM_ATTN_TIMING): cycle totals of the forward kernel's per-tile segments of
+// workgroup (1,0,0), wave 0, are written to the device address in LDM_ATTN_TIMING_BUF.
+#ifdef LDM_ATTN_TIMING
+#define ASTAMP(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); \
+                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define ASTAMP(var) do { } while (0)
+#endif
+
+__device__ __forceinline__ bool aligned_to_dev(const void *p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // 64 rows x DP columns, rows >= S and columns >= hd zero-filled
@@ -66,6 +78,36 @@ __device__ __forceinline__ void tile_load(const bf16_t *base, int64_t ld, int ro
       r[i] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
+// The same 64-row tile walk with the per-thread addressing done ONCE: chunk i of this thread is
+// (row rr[i], 16-byte column cc[i]) of every tile; a tile step adds 64 rows.
+template <int DP>
+struct TileWalk {
+  const bf16_t *p[AT<DP>::NCH];   // address of the chunk in tile 0 (clamped into the matrix when out of range)
+  int rr[AT<DP>::NCH];            // tile-relative row, or a huge value for columns >= hd
+  int64_t step;                   // 64 rows
+  __device__ __forceinline__ void init(const bf16_t *base, int64_t ld, int hd, int tid) {
+    step = 64 * ld;
+#pragma unroll
+    for (int i = 0; i < AT<DP>::NCH; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / AT<DP>::CPR, c8 = c - row * AT<DP>::CPR;
+      const bool col_ok = c8 * 8 < hd;
+      rr[i] = col_ok ? row : (1 << 30);
+      p[i] = base + (int64_t)row * ld + (col_ok ? c8 * 8 : 0);
+    }
+  }
+  // tile t (rows 64 t ..), rows >= S and columns >= hd zero-filled
+  __device__ __forceinline__ void load(int t, int S, uint4 (&r)[AT<DP>::NCH]) const {
+    const int64_t off = (int64_t)t * step;
+    const int lim = S - 64 * t;
+#pragma unroll
+    for (int i = 0; i < AT<DP>::NCH; ++i) {
+      if (rr[i] < lim) r[i] = *reinterpret_cast<const uint4 *>(p[i] + off);
+      else r[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+};
+
 template <int DP, int STR>
 __device__ __forceinline__ void tile_store(char *tile, int tid, const uint4 (&r)[AT<DP>::NCH]) {
 #pragma unroll
@@ -127,31 +169,58 @@ __device__ __forceinline__ void store_rows(bf16_t *dst_row, const f16_t (&acc)[A
     }
 }
 
-// store_rows with the transposed rotary rotation applied first (head dim == DP): the pair
+// Store a wave's 32 x DP accumulator tile (lane = row, registers over d) through LDS so that the
+// global stores are 16-byte pieces of CONTIGUOUS rows (a row-per-lane store is issue-bound:
+// every instruction touches 32 rows).  `wlds`: this wave's private 32 * RSTR bytes; the caller has
+// made sure the workgroup is done with whatever lived there.  rows_ok = rows of the tile inside
+// the matrix.
+template <int DP>
+__device__ __forceinline__ void store_tile_lds(char *wlds, bf16_t *dst, int64_t ld, const f16_t (&acc)[AT<DP>::ND],
+                                               float scale, int lane, int rows_ok, int hd) {
+  using T = AT<DP>;
+  const int half = lane >> 5, c = lane & 31;
+#pragma unroll
+  for (int db = 0; db < T::ND; ++db)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int d = db * 32 + 8 * r4 + 4 * half;
+      uint2 v;
+      v.x = pack_bf16x2(acc[db][4 * r4 + 0] * scale, acc[db][4 * r4 + 1] * scale);
+      v.y = pack_bf16x2(acc[db][4 * r4 + 2] * scale, acc[db][4 * r4 + 3] * scale);
+      *reinterpret_cast<uint2 *>(wlds + c * T::RSTR + d * 2) = v;
+    }
+  constexpr int NPIECE = 32 * T::CPR;
+#pragma unroll
+  for (int i = 0; i < (NPIECE + 63) / 64; ++i) {
+    const int idx = lane + 64 * i;
+    const int row = idx / T::CPR, piece = idx - row * T::CPR;
+    if (idx < NPIECE && row < rows_ok && piece * 8 < hd)
+      *reinterpret_cast<uint4 *>(dst + (int64_t)row * ld + piece * 8) =
+          *reinterpret_cast<const uint4 *>(wlds + row * T::RSTR + piece * 16);
+  }
+}
+
+// The transposed rotary rotation of an accumulator tile, in place (head dim == DP): the pair
 // (d, d + DP/2) of one row lives in ONE lane -- registers of block d/32 and of block
-// (d + DP/2)/32 -- so the rotation needs no exchange.  Forward (src/transformer.py:178-185):
+// (d + DP/2)/32 -- so it needs no exchange.  Forward (src/transformer.py:178-185):
 // y[d] = x[d] cos - x[d+h] sin, y[d+h] = x[d+h] cos + x[d] sin; this applies the transpose.
 template <int DP>
-__device__ __forceinline__ void store_rows_unrope(bf16_t *dst_row, const f16_t (&acc)[AT<DP>::ND], float scale,
-                                                  int half, const float *cos_row, const float *sin_row) {
+__device__ __forceinline__ void unrope_acc(f16_t (&acc)[AT<DP>::ND], float scale, int half, const float *cos_row,
+                                           const float *sin_row) {
   constexpr int H2 = DP / 2;
 #pragma unroll
   for (int d0 = 0; d0 < H2; d0 += 8) {
-    constexpr int dummy = 0; (void)dummy;
     const int lb = d0 / 32, lr = (d0 % 32) / 8;
     const int e0 = d0 + H2;
     const int hb = e0 / 32, hr = (e0 % 32) / 8;
     const int d = d0 + 4 * half;
     const f4 cs = ld4(cos_row + d), sn = ld4(sin_row + d);
-    f4 lo, hi;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gl = acc[lb][4 * lr + j], gh = acc[hb][4 * hr + j];
-      lo.v[j] = (gl * cs.v[j] + gh * sn.v[j]) * scale;
-      hi.v[j] = (gh * cs.v[j] - gl * sn.v[j]) * scale;
+      acc[lb][4 * lr + j] = (gl * cs.v[j] + gh * sn.v[j]) * scale;
+      acc[hb][4 * hr + j] = (gh * cs.v[j] - gl * sn.v[j]) * scale;
     }
-    st4(dst_row + d, lo);
-    st4(dst_row + d + H2, hi);
   }
 }
 
@@ -171,6 +240,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const int q = blockIdx.x * 128 + wave * 32 + c;
 
+#ifdef LDM_ATTN_TIMING
+  unsigned long long tk0;
+  ASTAMP(tk0);
+#endif
   bf8_t qf[T::NK];
 #pragma unroll
   for (int kk = 0; kk < T::NK; ++kk) qf[kk] = global_frag(qb, a.ld, q < S ? q : S - 1, true, kk, half, hd);
@@ -184,32 +257,51 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
 
   const int nt = (S + 63) / 64;
   uint4 kr[T::NCH], vr[T::NCH];
-  tile_load<DP>(kb, a.ld, 0, S, hd, tid, kr);
-  tile_load<DP>(vb, a.ld, 0, S, hd, tid, vr);
+  TileWalk<DP> kw, vw;
+  kw.init(kb, a.ld, hd, tid);
+  vw.init(vb, a.ld, hd, tid);
+  kw.load(0, S, kr);
+  vw.load(0, S, vr);
   tile_store<DP, T::RSTR>(Kt, tid, kr);
   tile_store<DP, T::TSTR>(Vt, tid, vr);
   __syncthreads();
 
+#ifdef LDM_ATTN_TIMING
+  unsigned long long ta[6] = {0, 0, 0, 0, 0, 0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+#endif
   for (int t = 0; t < nt; ++t) {
+    ASTAMP(s0);
     const int k0 = t * 64;
     if (t + 1 < nt) {
-      tile_load<DP>(kb, a.ld, k0 + 64, S, hd, tid, kr);
-      tile_load<DP>(vb, a.ld, k0 + 64, S, hd, tid, vr);
+      kw.load(t + 1, S, kr);
+      vw.load(t + 1, S, vr);
     }
     bool kok = (k0 + lane) < S;
     if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
     const unsigned long long valid = __ballot(kok);
+    ASTAMP(s1);
 
+    // S^T = K Q^T: the K fragments are read two MFMAs ahead of their use
     f16_t sacc[2];
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk) {
+    for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
+    {
+      constexpr int NF = 2 * T::NK, AHEAD = 2;
+      bf8_t kf[NF];
 #pragma unroll
-      for (int kk = 0; kk < T::NK; ++kk)
-        sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<T::RSTR>(Kt, kbk * 32 + c, kk, half), qf[kk],
-                                                            sacc[kbk], 0, 0, 0);
+      for (int f = 0; f < AHEAD; ++f) kf[f] = row_frag<T::RSTR>(Kt, (f / T::NK) * 32 + c, f % T::NK, half);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + AHEAD < NF) kf[f + AHEAD] = row_frag<T::RSTR>(Kt, ((f + AHEAD) / T::NK) * 32 + c, (f + AHEAD) % T::NK, half);
+        sacc[f / T::NK] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f], qf[f % T::NK], sacc[f / T::NK], 0, 0, 0);
+      }
     }
+#ifdef LDM_ATTN_TIMING
+    asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
+    ASTAMP(s2);
+#endif
     if (valid != ~0ull) {
       const unsigned long long vs = valid >> (4 * half);
 #pragma unroll
@@ -243,31 +335,60 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
 
+    ASTAMP(s3);
+    // O^T += V^T P^T: the V fragments are read two MFMAs ahead of their use
+    {
+      constexpr int NF = 4 * T::ND, AHEAD = 2;     // fragment f: key block f / ND (16 keys), head-dim block f % ND
+      bf8_t vfr[NF], pf[4];
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
+      for (int f = 0; f < AHEAD; ++f) vfr[f] = tr_frag<T::TSTR>(Vt, (f / T::ND) * 16, f % T::ND, lane);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int g4 = 0; g4 < 4; ++g4) {
         float tmp[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tmp[j] = sacc[kbk][8 * s + j];
-        const bf8_t pf = pack8(tmp);
-#pragma unroll
-        for (int db = 0; db < T::ND; ++db)
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<T::TSTR>(Vt, kbk * 32 + 16 * s, db, lane), pf,
-                                                             oacc[db], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) tmp[j] = sacc[g4 >> 1][8 * (g4 & 1) + j];
+        pf[g4] = pack8(tmp);
       }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + AHEAD < NF) vfr[f + AHEAD] = tr_frag<T::TSTR>(Vt, ((f + AHEAD) / T::ND) * 16, (f + AHEAD) % T::ND, lane);
+        oacc[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[f], pf[f / T::ND], oacc[f % T::ND], 0, 0, 0);
+      }
+    }
+#ifdef LDM_ATTN_TIMING
+    asm volatile("" : "+v"(oacc[0]));
+    ASTAMP(s4);
+#endif
     __syncthreads();
     if (t + 1 < nt) {
       tile_store<DP, T::RSTR>(Kt, tid, kr);
       tile_store<DP, T::TSTR>(Vt, tid, vr);
       __syncthreads();
     }
+#ifdef LDM_ATTN_TIMING
+    ASTAMP(s5);
+    ta[0] += s1 - s0; ta[1] += s2 - s1; ta[2] += s3 - s2; ta[3] += s4 - s3; ta[4] += s5 - s4; ta[5] += 1;
+#endif
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-  if (q < S) {
-    store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
-    if (half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
+  if (q < S && half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
+  {
+    const int q0 = blockIdx.x * 128 + wave * 32;   // the loop ended with a barrier: the K/V tiles are dead
+    if (a.ld_o % 8 == 0 && aligned_to_dev(a.o, 16))
+      store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.o + ((int64_t)b * S + q0) * a.ld_o + (int64_t)head * hd, a.ld_o,
+                         oacc, 1.0f / ltot, lane, S - q0, hd);
+    else if (q < S)
+      store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
   }
+#ifdef LDM_ATTN_TIMING
+  if (a.timing && tid == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) {
+    unsigned long long tk1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(tk1);
+    for (int i = 0; i < 6; ++i) a.timing[i] = ta[i];
+    a.timing[6] = tk1 - tk0;
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------- dQ
@@ -363,10 +484,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
       __syncthreads();
     }
   }
-  if (q < S) {
-    bf16_t *row = a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd;
-    if (a.rope_cos) store_rows_unrope<DP>(row, dq, a.rope_scale, half, a.rope_cos + (int64_t)q * (DP / 2), a.rope_sin + (int64_t)q * (DP / 2));
-    else store_rows<DP>(row, dq, 1.0f, half, hd);
+  {
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (a.rope_cos) unrope_acc<DP>(dq, a.rope_scale, half, a.rope_cos + (int64_t)qc * (DP / 2), a.rope_sin + (int64_t)qc * (DP / 2));
+    if (aligned_to_dev(a.dqkv, 16))
+      store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.dqkv + ((int64_t)b * S + q0) * a.ld + (int64_t)head * hd, a.ld, dq,
+                         1.0f, lane, S - q0, hd);
+    else if (q < S)
+      store_rows<DP>(a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd, dq, 1.0f, half, hd);
   }
 }
 
@@ -477,17 +602,26 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
       __syncthreads();
     }
   }
-  if (key < S) {
-    bf16_t *row = a.dqkv + ((int64_t)b * S + key) * a.ld + (int64_t)head * hd;
-    if (a.rope_cos) store_rows_unrope<DP>(row + D, dk, 1.0f, half, a.rope_cos + (int64_t)key * (DP / 2), a.rope_sin + (int64_t)key * (DP / 2));
-    else store_rows<DP>(row + D, dk, 1.0f, half, hd);
-    store_rows<DP>(row + 2 * D, dv, 1.0f, half, hd);
+  {
+    const int k0w = blockIdx.x * 128 + wave * 32;
+    if (a.rope_cos) unrope_acc<DP>(dk, 1.0f, half, a.rope_cos + (int64_t)keyc * (DP / 2), a.rope_sin + (int64_t)keyc * (DP / 2));
+    if (aligned_to_dev(a.dqkv, 16)) {
+      char *wl = smem + wave * 32 * T::RSTR;
+      bf16_t *row0 = a.dqkv + ((int64_t)b * S + k0w) * a.ld + (int64_t)head * hd;
+      store_tile_lds<DP>(wl, row0 + D, a.ld, dk, 1.0f, lane, S - k0w, hd);
+      store_tile_lds<DP>(wl, row0 + 2 * D, a.ld, dv, 1.0f, lane, S - k0w, hd);
+    } else if (key < S) {
+      bf16_t *row = a.dqkv + ((int64_t)b * S + key) * a.ld + (int64_t)head * hd;
+      store_rows<DP>(row + D, dk, 1.0f, half, hd);
+      store_rows<DP>(row + 2 * D, dv, 1.0f, half, hd);
+    }
   }
 }
 
 template <int DP>
 int flash_fwd_launch(const FArgs &a, hipStream_t s) {
-  const size_t lds = 64 * AT<DP>::RSTR + 64 * AT<DP>::TSTR;
+  size_t lds = 64 * AT<DP>::RSTR + 64 * AT<DP>::TSTR;
+  if (lds < (size_t)128 * AT<DP>::RSTR) lds = (size_t)128 * AT<DP>::RSTR;   // the epilogue stages O through LDS
   dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
   hipLaunchKernelGGL(flash_fwd_k<DP>, grid, dim3(256), lds, s, a);
   LDM_CHECK_LAUNCH();
@@ -519,6 +653,9 @@ int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
   FArgs a{};
   a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
   a.o = o; a.ld_o = ld_o; a.lse = lse;
+#ifdef LDM_ATTN_TIMING
+  { const char *tb = getenv("LDM_ATTN_TIMING_BUF"); a.timing = tb ? (unsigned long long *)strtoull(tb, nullptr, 0) : nullptr; }
+#endif
   int rc = check(a);
   if (rc) return rc;
   if (!aligned_to(qkv, 16) || !aligned_to(o, 8)) return LDM_E_ALIGN;

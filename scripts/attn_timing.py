@@ -1,0 +1,27 @@
+"""Per-segment cycle breakdown of the attention forward kernel (needs `make timing`)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+dev = torch.device("cuda:0")
+buf = torch.zeros(8, dtype=torch.int64, device=dev)
+os.environ["LDM_ATTN_TIMING_BUF"] = str(buf.data_ptr())
+os.environ["LDM_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                     "language-diffusion-model_amd", "lib", "libldm_hip_timing.so")
+from src import _native as N
+B, S, H, hd = 128, 512, 8, 96
+D = H * hd
+qkv = torch.randn(B * S, 3 * D, device=dev).bfloat16()
+o = torch.empty(B * S, D, device=dev, dtype=torch.bfloat16)
+saved = torch.empty(N.lib().ldm_attn_saved_bytes(1, B, H, S, hd), dtype=torch.uint8, device=dev)
+def run():
+    N.check(N.lib().ldm_attn_fwd(1, qkv.data_ptr(), 3 * D, None, B, H, S, hd, o.data_ptr(), D, saved.data_ptr(), N.stream()), "fwd")
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+t = buf.cpu().double()
+n = t[5].item()
+names = ["issue next-tile loads", "S = K Q^T (12 MFMA)", "softmax", "O += V^T P (12 MFMA)", "barriers + tile store"]
+print(f"fwd {e0.elapsed_time(e1) * 1e3:.1f} us (instrumented); per tile of one wave, cycles:")
+for i, nm in enumerate(names):
+    print(f"  {nm:28s} {t[i].item() / n:8.1f}")
+print(f"  total {t[:5].sum().item() / n:8.1f}  tiles {int(n)}; whole kernel for that wave {t[6].item():.0f} cycles; workgroups per slot {B * H * (S // 128) / 512:.0f}")
