@@ -21,12 +21,15 @@ for name, ta, tb, M, Nn, K in shapes:
     a = torch.randn((K, M) if ta else (M, K), device=dev).bfloat16()
     b = torch.randn((Nn, K) if tb else (K, Nn), device=dev).bfloat16()
     acc = name == "dw"
+    use_res = bool(os.environ.get("RES")) and name == "fwd"
+    bias = torch.randn(Nn, device=dev) if use_res else None
+    res = torch.randn(M, Nn, device=dev).bfloat16() if use_res else None
     c = torch.zeros(M, Nn, device=dev, dtype=torch.float32 if acc else torch.bfloat16)
     def run():
         if acc:
             N.check(N.lib().ldm_gemm_acc(1, ta, tb, M, Nn, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), Nn, N.stream()), "acc")
         else:
-            N.check(N.lib().ldm_gemm(1, 1, ta, tb, M, Nn, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), Nn, None, None, 0, N.stream()), "gemm")
+            N.check(N.lib().ldm_gemm(1, 1, ta, tb, M, Nn, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), Nn, N.ptr(bias), N.ptr(res), Nn if use_res else 0, N.stream()), "gemm")
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
