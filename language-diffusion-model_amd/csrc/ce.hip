@@ -185,27 +185,40 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_k(const T *logits, CeArgs a, 
 }
 
 // Compaction: rows[0..count) = indices of the participating rows in ascending order.
-// One 1024-thread block; each thread owns a contiguous run of rows.
+// One 1024-thread block walks the rows 1024 at a time (coalesced flag reads): ballot + popcount
+// inside a wave, the 16 wave counts through LDS.
 __global__ __launch_bounds__(1024) void ce_compact_k(CeArgs a, int *rows, int *count) {
-  __shared__ int part[1024];
-  const int64_t per = (a.T + 1023) / 1024;
-  const int64_t r0 = (int64_t)threadIdx.x * per;
-  const int64_t r1 = (r0 + per < a.T) ? r0 + per : a.T;
-  int c = 0;
-  for (int64_t r = r0; r < r1; ++r) c += row_active(a, r) ? 1 : 0;
-  part[threadIdx.x] = c;
-  __syncthreads();
-  // inclusive scan (Hillis-Steele) over 1024 partial counts
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  __shared__ int wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int base = 0;   // rows found before this chunk (the same value in every thread)
+  constexpr int G = 8;   // chunks whose flags are fetched together (independent loads in flight)
+  for (int64_t g0 = 0; g0 < a.T; g0 += (int64_t)G * 1024) {
+    bool acts[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int64_t r = g0 + j * 1024 + threadIdx.x;
+      acts[j] = r < a.T && row_active(a, r);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      if (g0 + j * 1024 >= a.T) break;                    // block-uniform
+      const int64_t r = g0 + j * 1024 + threadIdx.x;
+      const unsigned long long m = __ballot(acts[j]);
+      if (lane == 0) wsum[wid] = __popcll(m);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const int c = wsum[w];
+        before += w < wid ? c : 0;
+        total += c;
+      }
+      if (acts[j]) rows[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (int)r;
+      base += total;
+      __syncthreads();
+    }
   }
-  int pos = part[threadIdx.x] - c;
-  for (int64_t r = r0; r < r1; ++r)
-    if (row_active(a, r)) rows[pos++] = (int)r;
-  if (threadIdx.x == 1023) count[0] = part[1023];
+  if (threadIdx.x == 0) count[0] = base;
 }
 
 // Backward into the COMPACT layout: block i handles compact row i (source row rows[i]);

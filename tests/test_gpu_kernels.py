@@ -372,3 +372,20 @@ def test_attention_bwd_fused_unrope_matches_two_pass(dev, B, S, H, hd):
         grads[fused] = x.grad.float()
     assert rel_err(grads[True], grads[False]) < 6e-3
     assert torch.equal(grads[True].view(B, S, 3, D)[:, :, 2], grads[False].view(B, S, 3, D)[:, :, 2])   # dv untouched
+
+
+@pytest.mark.parametrize("T", [1, 63, 1024, 1250, 65536 + 17])
+def test_ce_compact_rows(dev, T):
+    """rows[0..count) = ascending indices where masked id == mask token and attention == 1."""
+    from src import _native as Nn
+    torch.manual_seed(T)
+    ids = torch.where(torch.rand(T, device=dev) < 0.4, 103, 2000).to(torch.int64)
+    att = (torch.rand(T, device=dev) < 0.8).to(torch.uint8)
+    rows = torch.full((T,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    Nn.check(Nn.lib().ldm_ce_compact_rows(T, 1, ids.data_ptr(), 103, None, att.data_ptr(), rows.data_ptr(),
+                                          cnt.data_ptr(), Nn.stream()), "ldm_ce_compact_rows")
+    want = torch.nonzero((ids == 103) & (att != 0)).flatten().to(torch.int32)
+    assert int(cnt.item()) == want.numel()
+    assert torch.equal(rows[:want.numel()], want)
+    assert bool((rows[want.numel():] == -1).all())
