@@ -389,3 +389,49 @@ def test_ce_compact_rows(dev, T):
     assert int(cnt.item()) == want.numel()
     assert torch.equal(rows[:want.numel()], want)
     assert bool((rows[want.numel():] == -1).all())
+
+
+@pytest.mark.parametrize("tb", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(8192, 2304, 256), (8192, 2560, 96), (8192, 2304, 128), (10240, 2176, 160),
+                                   (16384 + 40, 1280 + 8, 192)])
+def test_gemm_persistent_many_tiles(dev, tb, M, N, K):
+    """More 256x256 tiles than CUs: every workgroup walks several tiles (next tile's operands fetched
+    before the epilogue, store-aware waits, ragged last tiles), with and without bias / residual."""
+    torch.manual_seed(5)
+    a = torch.randn(M, K, device=dev).bfloat16()
+    b = torch.randn((N, K) if tb else (K, N), device=dev).bfloat16()
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev).bfloat16()
+    ref = a.double() @ (b.double().t() if tb else b.double())
+    c = _gemm_call(a, b, 0, tb, M, N, K, torch.bfloat16)
+    assert rel_err(c.float(), ref) < 4e-3
+    c = _gemm_call(a, b, 0, tb, M, N, K, torch.bfloat16, bias)
+    assert rel_err(c.float(), ref + bias.double()) < 4e-3
+    c = _gemm_call(a, b, 0, tb, M, N, K, torch.bfloat16, bias, res)
+    assert rel_err(c.float(), ref + bias.double() + res.double()) < 4e-3
+    c = _gemm_call(a, b, 0, tb, M, N, K, torch.float32, bias)
+    assert rel_err(c, ref + bias.double()) < 1e-5
+
+
+def test_gemm_rows_dyn_many_tiles(dev):
+    """Device-side row count with more populated tiles than CUs, bias, identity and mapped rows."""
+    from src import _native as Nn
+    torch.manual_seed(6)
+    M, N, K, cnt_v = 12288, 2304, 128, 9000
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = torch.randn(N, K, device=dev).bfloat16()
+    bias = torch.randn(N, device=dev)
+    cnt = torch.tensor([cnt_v], dtype=torch.int32, device=dev)
+    c = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    Nn.check(Nn.lib().ldm_gemm_rows_dyn(1, 1, M, N, K, a.data_ptr(), K, w.data_ptr(), K, c.data_ptr(), N,
+                                        bias.data_ptr(), cnt.data_ptr(), None, Nn.stream()), "rows_dyn")
+    ref = a[:cnt_v].double() @ w.double().t() + bias.double()
+    assert rel_err(c[:cnt_v].float(), ref) < 4e-3
+    assert bool((c[cnt_v:] == 7.0).all()), "rows past the device-side count must not be written"
+    perm = torch.randperm(M, device=dev)[:cnt_v].to(torch.int32)
+    c2 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    Nn.check(Nn.lib().ldm_gemm_rows_dyn(1, 1, M, N, K, a.data_ptr(), K, w.data_ptr(), K, c2.data_ptr(), N,
+                                        None, cnt.data_ptr(), perm.data_ptr(), Nn.stream()), "rows_dyn map")
+    want = torch.zeros(M, N, dtype=torch.float64, device=dev)
+    want[perm.long()] = a[:cnt_v].double() @ w.double().t()
+    assert rel_err(c2.float(), want) < 4e-3

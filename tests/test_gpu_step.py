@@ -7,6 +7,8 @@ bit-exact, loss and every parameter gradient within 1e-5 (fp32) / 2e-2 (bf16) re
 import types
 
 import numpy as np
+import math
+
 import pytest
 import torch
 
@@ -237,3 +239,63 @@ def test_fused_head_loss_equals_dense_composition(dev, p_mask):
         mine = torch.cat([res[True][1][n].float().cpu().reshape(-1) for n in names])
         ref = torch.cat([oparams[n].grad.reshape(-1) for n in names])
         assert rel_err(mine, ref) < 2e-2
+
+
+def test_full_size_model_properties(dev):
+    """configs/default.yaml model at full depth and S=512 (too big for the CPU oracle): properties
+    that do not depend on size.  (1) the trainer-step loss (LM head on the rows the loss reads)
+    equals model() + variational_lower_bound_loss() and so do the gradients; (2) the loss at random
+    init is near ln(V); (3) embedding rows of ids that never occur in the masked input get exactly
+    zero gradient; (4) with nothing masked the loss is 0 and every gradient is 0."""
+    import random
+    import types
+    from src.loss import variational_lower_bound_loss
+    from src.masking_strategy import create_masking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    torch.manual_seed(11)
+    cfg = DiffusionTransformerConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=8, dim_feedforward=1024,
+                                     dropout=0.0, layer_norm_eps=1e-12, max_position_embeddings=512)
+    tr = DiffusionTransformer(cfg).to(dev).set_compute_dtype(torch.bfloat16)
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None).to(dev)
+    B, S = 4, 512
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1000, 30522, (B, S), generator=g)
+    ids[:, 0] = 101
+    lens = torch.tensor([512, 400, 300, 512])
+    att = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ids = torch.where(att == 1, ids, torch.zeros_like(ids))
+    ids, att = ids.to(dev), att.to(dev)
+    t = torch.tensor([0.45], device=dev)
+
+    def run(fused):
+        tr.zero_grad(set_to_none=True)
+        torch.manual_seed(99)                       # same mask draw in both runs
+        if fused:
+            loss = model.training_loss(ids, att, t=t)
+        else:
+            logits, masked, _ = model(ids, att, t=t)
+            loss = variational_lower_bound_loss(logits, ids, masked, 103, att)
+        loss.backward()
+        return loss.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()}
+
+    lf, gf = run(True)
+    ld, gd = run(False)
+    assert math.isfinite(lf) and 8.0 < lf < 13.0            # ~ln(30522) = 10.3 at random init
+    assert abs(lf - ld) <= 1e-5 * abs(ld)
+    for n in gd:
+        assert rel_err(gf[n], gd[n]) < 5e-3, n
+    # (3) ids absent from the masked input: exactly zero embedding gradient
+    torch.manual_seed(99)
+    masked, _ = model.masking_strategy.apply_random_mask(ids, 0.45)
+    present = torch.zeros(30522, dtype=torch.bool, device=dev)
+    present[masked.flatten()] = True
+    assert float(gf["embedding.weight"][~present].abs().max()) == 0.0
+    assert float(gf["embedding.weight"][103].abs().max()) > 0.0
+    # (4) nothing masked
+    tr.zero_grad(set_to_none=True)
+    loss0 = model.training_loss(ids, att, t=torch.tensor([0.0], device=dev))
+    loss0.backward()
+    assert loss0.item() == 0.0
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in tr.parameters())
