@@ -615,7 +615,17 @@ int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N,
   const bool use128 = N < 256 || (N % 256 != 0 && N % 256 <= 128);
   g.tiles_m = (int)ceil_div(M, BM);
   g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
-  if ((int64_t)g.tiles_m * g.tiles_n < 200) return LDM_E_SHAPE;   // no K split with a device-side K
+  const int64_t nt = (int64_t)g.tiles_m * g.tiles_n;
+  if (nt < 200) return LDM_E_SHAPE;
+  // K splits (the kernel divides the device-side K among them) only to even out the rounds of the
+  // 256 persistent workgroups: 360 tiles are 1.4 rounds, 720 half-K items are 2.8
+  int best = 1;
+  double best_eff = quant_eff(nt);
+  for (int sp = 2; sp <= 3; ++sp) {
+    const double e = quant_eff(nt * sp) - 0.03 * (sp - 1);   // each split adds one pass of float atomics
+    if (e > best_eff + 0.05) { best = sp; best_eff = e; }
+  }
+  g.splits = best;
   g.dyn_k = dyn_k;
   g.rowsum = rowsum;
   const bool akc = !transA, bkc = transB != 0;
