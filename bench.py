@@ -35,6 +35,8 @@ CONFIGS = {
     # reference configs/default.yaml:8-15 with len(BertTokenizer) = 30522
     "default": dict(vocab_size=30522, d_model=768, nhead=8, num_layers=8, dim_feedforward=1024),
     "1b": dict(vocab_size=32000, d_model=2048, nhead=16, num_layers=16, dim_feedforward=5632),
+    # LLaDA-8B layer shape at reduced depth (a single-GPU sanity / kernel-shape run, not a benchmark)
+    "8b-2layer": dict(vocab_size=126464, d_model=4096, nhead=32, num_layers=2, dim_feedforward=12288),
     "tiny": dict(vocab_size=200, d_model=64, nhead=2, num_layers=2, dim_feedforward=128),
 }
 

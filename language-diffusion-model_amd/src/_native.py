@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
+ABI_VERSION = 4   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -85,6 +86,10 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        got = handle.ldm_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION}: rebuild it "
+                               "(`make -C language-diffusion-model_amd`)")
         _lib = handle
     return _lib
 

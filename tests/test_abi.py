@@ -26,6 +26,6 @@ def test_library_exports_header_symbols():
 
 def test_version_and_error_strings():
     from src import _native as N
-    assert N.lib().ldm_abi_version() == 4
+    assert N.lib().ldm_abi_version() == N.ABI_VERSION
     assert b"aligned" in N.lib().ldm_error_string(-2)
     assert N.lib().ldm_rmsnorm_bwd_ws_floats(100, 64) > 0

@@ -51,8 +51,9 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(100 + rank)
         x = torch.randn(5 + rank, 16, generator=g)
         dp(x, use_extra).pow(2).mean().backward()
-        out[step] = {n: p.grad.clone() for n, p in net.named_parameters()}
-    q.put((rank, out, {n: p.detach().clone() for n, p in net.named_parameters()}))
+        out[step] = {n: p.grad.clone().numpy() for n, p in net.named_parameters()}
+    # numpy payloads: torch tensors would travel as shared-memory handles that die with this process
+    q.put((rank, out, {n: p.detach().clone().numpy() for n, p in net.named_parameters()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,7 +76,7 @@ def test_bucketed_allreduce_two_ranks():
     torch.manual_seed(0)
     ref_net = _Net()
     for n, p in ref_net.named_parameters():
-        assert torch.equal(res[0][1][n], p.detach()) and torch.equal(res[1][1][n], p.detach())
+        assert torch.equal(torch.from_numpy(res[0][1][n]), p.detach()) and torch.equal(torch.from_numpy(res[1][1][n]), p.detach())
     for step, extras in enumerate([(True, False), (True, True)]):
         want = {}
         for r in range(2):
@@ -83,4 +84,4 @@ def test_bucketed_allreduce_two_ranks():
                 want[n] = want.get(n, 0) + g / 2
         for r in range(2):
             for n, g in res[r][0][step].items():
-                assert torch.allclose(g, want[n], rtol=1e-6, atol=1e-7), (step, r, n)
+                assert torch.allclose(torch.from_numpy(g), want[n], rtol=1e-6, atol=1e-7), (step, r, n)
