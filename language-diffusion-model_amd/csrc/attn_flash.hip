@@ -391,6 +391,241 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
 #endif
 }
 
+// =========================================================================== LDS-DMA variants
+// Head dims 96 and 128: the streamed 64-row tiles go global -> LDS by 16-byte LDS-DMA (no
+// register staging, no ds_write, one barrier per tile, two buffers).  An LDS-DMA instruction
+// writes 1 KiB of CONTIGUOUS LDS, so rows cannot be padded; instead every row has a 256-byte
+// pitch (16 chunks of 16 B, 12 or 16 of them used) and chunk c of row r sits at position
+// c ^ swz2(r): conflict-free both for the by-row reads (16 lanes = 16 rows, one chunk) and for
+// the transposing reads (32 lanes = 4 rows x 4 chunks).  The swizzle is applied to the SOURCE
+// address of each lane; lanes whose source chunk does not exist (c >= hd/8) are masked off.
+constexpr int PITCH2 = 256;
+constexpr int TILE2 = 64 * PITCH2;
+__device__ __forceinline__ int swz2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+#define LDS_PTR2(p) ((__attribute__((address_space(3))) void *)(p))
+#define GLB_PTR2(p) ((const __attribute__((address_space(1))) void *)(p))
+
+// The 4 LDS-DMA pieces (4 rows x 256 B each) of a 64-row tile that one of the 4 waves issues.
+// Lanes whose chunk does not exist (head dim 96: chunks 12..15) fetch another chunk of the same
+// row instead of being masked off: what they write is never read, and the issue stays branch-free.
+struct TileDma {
+  const bf16_t *p[4];   // source of this lane in tile 0, piece i
+  int64_t step;         // 64 rows
+  int rr;
+  __device__ __forceinline__ void init(const bf16_t *base, int64_t ld, int hd, int wave, int lane) {
+    step = 64 * ld;
+    rr = lane >> 4;
+    const int pc = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 4 + rr;
+      int sc = pc ^ swz2(row);
+      if (sc * 8 >= hd) sc &= 3;
+      p[i] = base + (int64_t)row * ld + sc * 8;
+    }
+  }
+  // tile t -> image `img`; rows >= S re-read row S-1 (finite values; their scores are masked)
+  __device__ __forceinline__ void issue(int t, int S, int64_t ld, char *img, int wave) const {
+    const int lim = S - 64 * t;
+    if (lim >= 64) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR2(p[i] + (int64_t)t * step), LDS_PTR2(img + (wave * 4 + i) * 1024),
+                                         16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + rr;
+        const bf16_t *src = p[i] + (int64_t)t * step - (int64_t)(row >= lim ? row - (lim - 1) : 0) * ld;
+        __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(img + (wave * 4 + i) * 1024), 16, 0, 0);
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ bf8_t row_frag2(const char *tile, int row, int kk, int half) {
+  return *reinterpret_cast<const bf8_t *>(tile + row * PITCH2 + (((kk * 2 + half) ^ swz2(row)) << 4));
+}
+__device__ __forceinline__ bf8_t tr_frag2(const char *tile, int rbase, int dblk, int lane) {
+  const int half = lane >> 5, gg = (lane >> 4) & 1, i = lane & 15;
+  const int r0 = rbase + 4 * half + (i >> 2), r1 = r0 + 8;
+  const int d0 = dblk * 32 + 16 * gg + 4 * (i & 3);
+  const int ch = d0 >> 3, in = (d0 & 7) * 2;
+  const char *a0 = tile + r0 * PITCH2 + ((ch ^ swz2(r0)) << 4) + in;
+  const char *a1 = tile + r1 * PITCH2 + ((ch ^ swz2(r1)) << 4) + in;
+  s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0));
+  s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a1));
+  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8_t, v);
+}
+
+// Transposing reads issued from inline asm: the compiler orders nothing around them (its own
+// transposing-read intrinsic makes it drain every LDS-DMA in flight first), so the caller waits
+// with tr_wait2 before it uses the registers.  `base` = per-lane byte address of (r0, dblk)
+// within an image; `off` = image + 16-row-block offset, the second read is 8 rows on.
+struct TrAddr {
+  unsigned a0, a1;
+  __device__ __forceinline__ void init(int dblk, int lane) {
+    const int half = lane >> 5, gg = (lane >> 4) & 1, i = lane & 15;
+    const int r0 = 4 * half + (i >> 2), r1 = r0 + 8;
+    const int d0 = dblk * 32 + 16 * gg + 4 * (i & 3);
+    const int ch = d0 >> 3, in = (d0 & 7) * 2;
+    a0 = r0 * PITCH2 + ((ch ^ swz2(r0)) << 4) + in;
+    a1 = r1 * PITCH2 + ((ch ^ swz2(r1)) << 4) + in;
+  }
+};
+__device__ __forceinline__ void tr_issue2(const TrAddr &ta, unsigned off, s4_t &lo, s4_t &hi) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ta.a0 + off));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ta.a1 + off));
+}
+template <int N>
+__device__ __forceinline__ bf8_t tr_wait2(s4_t &lo, s4_t &hi) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
+  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8_t, v);
+}
+__device__ __forceinline__ unsigned lds_off(const void *p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
+  using T = AT<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, c = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, hd = a.hd;
+  const int64_t D = (int64_t)a.H * hd;
+  const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
+  const bf16_t *kb = qb + D, *vb = qb + 2 * D;
+  const int q = blockIdx.x * 128 + wave * 32 + c;
+
+  TrAddr vta[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i) vta[i].init(i, lane);
+  TileDma kd, vd;
+  kd.init(kb, a.ld, hd, wave, lane);
+  vd.init(vb, a.ld, hd, wave, lane);
+  kd.issue(0, S, a.ld, smem, wave);
+  vd.issue(0, S, a.ld, smem + TILE2, wave);
+
+  bf8_t qf[T::NK];
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk) qf[kk] = global_frag(qb, a.ld, q < S ? q : S - 1, true, kk, half, hd);
+
+  f16_t oacc[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  const int nt = (S + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * 64;
+    const char *Kt = smem + (t & 1) * 2 * TILE2;
+    const char *Vt = Kt + TILE2;
+    bool kok = (k0 + lane) < S;
+    if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
+    const unsigned long long valid = __ballot(kok);
+    // tile t has landed (this wave's pieces); after the barrier it is visible to all and every
+    // wave is done with tile t-1, whose buffer the next tile's LDS-DMA then refills
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) {
+      char *nb = smem + ((t + 1) & 1) * 2 * TILE2;
+      kd.issue(t + 1, S, a.ld, nb, wave);
+      vd.issue(t + 1, S, a.ld, nb + TILE2, wave);
+    }
+
+    f16_t sacc[2];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
+    {
+      constexpr int NF = 2 * T::NK, AHEAD = 2;
+      bf8_t kf[NF];
+#pragma unroll
+      for (int f = 0; f < AHEAD; ++f) kf[f] = row_frag2(Kt, (f / T::NK) * 32 + c, f % T::NK, half);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + AHEAD < NF) kf[f + AHEAD] = row_frag2(Kt, ((f + AHEAD) / T::NK) * 32 + c, (f + AHEAD) % T::NK, half);
+        sacc[f / T::NK] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f], qf[f % T::NK], sacc[f / T::NK], 0, 0, 0);
+      }
+    }
+    if (valid != ~0ull) {
+      const unsigned long long vs = valid >> (4 * half);
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!((vs >> (kbk * 32 + acc_row(r))) & 1ull)) sacc[kbk][r] = -INFINITY;
+    }
+    float mx = m;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kbk][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mu = (mx == -INFINITY) ? 0.f : mx;
+    const float alpha = fast_exp2((m - mu) * LOG2E);
+    m = mx;
+    float ps = 0.f;
+    const float mneg = -mu * LOG2E;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(sacc[kbk][r], LOG2E, mneg));
+        sacc[kbk][r] = p;
+        ps += p;
+      }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    {
+      constexpr int NF = 4 * T::ND;
+      const unsigned vo = lds_off(Vt);
+      s4_t lo[NF], hi[NF];
+      bf8_t pf[4];
+      tr_issue2(vta[0], vo, lo[0], hi[0]);
+      tr_issue2(vta[1 % T::ND], vo + (1 / T::ND) * 16 * PITCH2, lo[1], hi[1]);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = sacc[g4 >> 1][8 * (g4 & 1) + j];
+        pf[g4] = pack8(tmp);
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) tr_issue2(vta[(f + 2) % T::ND], vo + ((f + 2) / T::ND) * 16 * PITCH2, lo[f + 2], hi[f + 2]);
+        // reads in flight after this issue: fragments f .. min(f+2, NF-1), two each
+        const bf8_t vf = (f + 2 < NF) ? tr_wait2<4>(lo[f], hi[f]) : (f + 1 < NF) ? tr_wait2<2>(lo[f], hi[f]) : tr_wait2<0>(lo[f], hi[f]);
+        oacc[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[f / T::ND], oacc[f % T::ND], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave is done with the tiles: the epilogue re-uses the LDS
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (q < S && half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
+  {
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (a.ld_o % 8 == 0 && aligned_to_dev(a.o, 16))
+      store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.o + ((int64_t)b * S + q0) * a.ld_o + (int64_t)head * hd, a.ld_o,
+                         oacc, 1.0f / ltot, lane, S - q0, hd);
+    else if (q < S)
+      store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
+  }
+}
+
 // --------------------------------------------------------------------------- dQ
 template <int DP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
@@ -629,6 +864,30 @@ int flash_fwd_launch(const FArgs &a, hipStream_t s) {
 }
 
 template <int DP>
+int flash2_fwd_launch(const FArgs &a, hipStream_t s) {
+  constexpr int lds = 4 * TILE2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)flash2_fwd_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  hipLaunchKernelGGL(flash2_fwd_k<DP>, grid, dim3(256), lds, s, a);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+// LDM_ATTN_DMA=0 pins the register-staged kernels (A/B measurements)
+bool attn_dma_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("LDM_ATTN_DMA");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <int DP>
 int flash_bwd_launch(const FArgs &a, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
   hipLaunchKernelGGL(flash_bwd_dq_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
@@ -661,6 +920,10 @@ int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
   if (!aligned_to(qkv, 16) || !aligned_to(o, 8)) return LDM_E_ALIGN;
   if (hd <= 32) return flash_fwd_launch<32>(a, s);
   if (hd <= 64) return flash_fwd_launch<64>(a, s);
+  if (attn_dma_enabled() && a.ld % 8 == 0) {
+    if (hd == 96) return flash2_fwd_launch<96>(a, s);
+    if (hd == 128) return flash2_fwd_launch<128>(a, s);
+  }
   if (hd <= 96) return flash_fwd_launch<96>(a, s);
   return flash_fwd_launch<128>(a, s);
 }

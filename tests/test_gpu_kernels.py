@@ -323,7 +323,8 @@ def _attn_ref(qkv, key_valid, B, S, H, hd):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,H,hd,ragged", [(3, 10, 4, 8, True), (2, 48, 2, 96, True), (2, 130, 2, 64, True),
-                                             (1, 256, 2, 128, False), (2, 200, 3, 32, True), (1, 512, 8, 96, False)])
+                                             (1, 256, 2, 128, False), (2, 200, 3, 32, True), (1, 512, 8, 96, False),
+                                             (2, 200, 2, 128, True), (2, 130, 3, 96, True), (1, 3, 1, 96, False)])
 def test_attention_fwd_bwd(dev, dtype, B, S, H, hd, ragged):
     from src import ops
     from src.transformer import RotaryPositionEmbedding
