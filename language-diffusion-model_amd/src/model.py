@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from . import ops
+
 
 class DiffusionLanguageModel(nn.Module):
     def __init__(self, transformer, tokenizer, masking_strategy, remasking_strategy=None) -> None:
@@ -27,6 +29,8 @@ class DiffusionLanguageModel(nn.Module):
                 t: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor]:
         # src/model.py:59-64: one python-RNG scalar per call unless t is given; a
         # one-element tensor is unwrapped, anything else is passed through.
+        if torch.is_grad_enabled():
+            ops.begin_step()
         if t is None:
             mask_prob = random.random()
         else:
@@ -42,6 +46,8 @@ class DiffusionLanguageModel(nn.Module):
         as the reference trainer composes them (src/trainer.py:126-134), with the LM head
         evaluated only at the positions the loss reads.  Consumes the python RNG exactly as
         forward() does (one random.random() per call)."""
+        if torch.is_grad_enabled():
+            ops.begin_step()
         if t is None:
             mask_prob = random.random()
         else:

@@ -97,6 +97,44 @@ class PackedWeights:
         return self.w, self.b
 
 
+class _ZeroPool:
+    """Zero-filled fp32 buffers for the weight gradients of ONE backward pass, carved from a single
+    allocation: one memset instead of one fill per projection.  ``begin()`` marks a new training
+    step; the size asked for in the previous step is what the next one allocates up front.  A
+    request that does not fit (first step, changed shapes, a second backward) gets its own
+    ``torch.zeros``."""
+
+    def __init__(self):
+        self.want = 0
+        self.used = 0
+        self.buf = None
+        self.off = 0
+
+    def begin(self):
+        self.want, self.used, self.buf, self.off = self.used, 0, None, 0
+
+    def take(self, numel: int, device) -> Tensor:
+        step = _round_up(numel, 64)
+        self.used += step
+        if self.want:
+            if self.buf is None:
+                self.buf = torch.zeros(self.want, dtype=torch.float32, device=device)
+                self.off = 0
+            if self.buf.device == device and self.off + numel <= self.buf.numel():
+                v = self.buf[self.off:self.off + numel]
+                self.off += step
+                return v
+        return torch.zeros(numel, dtype=torch.float32, device=device)
+
+
+ZERO_POOL = _ZeroPool()
+
+
+def begin_step():
+    """Called once per training step, before the forward (model.forward / training_loss)."""
+    ZERO_POOL.begin()
+
+
 # Optional per-launch timing for the benchmark: when set to a dict, every GEMM whose tag is a
 # key gets a pair of events recorded around its launch on the launching stream; the list
 # under the key collects (start, end, flops) triples.
@@ -175,7 +213,7 @@ class _PackedLinear(torch.autograd.Function):
             dx = torch.empty(T, k, dtype=dt, device=g.device)
             _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag=pack.name + ".dx")
         # dW and db share one zeroed buffer ([n_pad, k] then [n_pad]) and, for bf16, one kernel
-        dwb = torch.zeros(n_pad * k + n_pad, dtype=torch.float32, device=g.device)
+        dwb = ZERO_POOL.take(n_pad * k + n_pad, g.device)
         dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
         rc = -2
         if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
@@ -219,7 +257,7 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
     xc = torch.empty(Tp, k, dtype=torch.bfloat16, device=dev)
     N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), count.data_ptr(), T, k,
                                 xc.data_ptr(), st), "ldm_gather_rows")
-    dwb = torch.zeros(n_pad * k + n_pad, dtype=torch.float32, device=dev)
+    dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
     dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
     rc = lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, Tp, dlc.data_ptr(), n_pad, xc.data_ptr(), k, dw.data_ptr(), k,
                                count.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None, st)
@@ -274,7 +312,7 @@ class _Embedding(torch.autograd.Function):
         (ids_c,) = ctx.saved_tensors
         V, d = ctx.shape
         g = g.contiguous()
-        dtab = torch.zeros(V, d, dtype=torch.float32, device=g.device)
+        dtab = ZERO_POOL.take(V * d, g.device).view(V, d)
         N.check(N.lib().ldm_embed_bwd(ids_c.data_ptr(), g.data_ptr(), N.dtype_code(g.dtype), ids_c.numel(), d, V,
                                       ctx.hot_id, dtab.data_ptr(), N.stream()), "ldm_embed_bwd")
         return None, dtab, None, None
@@ -632,7 +670,7 @@ class _HeadMaskedCE(torch.autograd.Function):
             dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
             N.check(lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, lc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(),
                                           k, None, cnt.data_ptr(), rows.data_ptr(), st), "ldm_gemm_rows_dyn")
-        dwb = torch.zeros(n_pad * k + n_pad, dtype=torch.float32, device=dev)
+        dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
         dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
         N.check(lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, _round_up(T, 64), lc.data_ptr(), n_pad, xc.data_ptr(), k,
                                       dw.data_ptr(), k, cnt.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None,
