@@ -235,6 +235,33 @@ int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, c
 int ldm_colsum_rows_dyn(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
                         const int32_t *m_dev, void *stream);
 
+/* ---------------------------------------------------------------- reverse process: token selection
+ * ldm_sample_tokens replaces what DiffusionLanguageModel.generate / sample do with the logits
+ * (src/model.py:93-105 and :167-177): for every row whose id is mask_id (all_rows != 0: for
+ * every row) pick a column of logits[T, V] (row stride ld):
+ *   temperature == 0: argmax, the first maximum as torch.argmax returns it;
+ *   temperature  > 0: argmax(logit / temperature + Gumbel noise), a draw from
+ *                     softmax(logits / temperature) -- the distribution the reference hands to
+ *                     torch.multinomial; the noise is Philox4x32-10 keyed by (seed, offset), so
+ *                     the STREAM differs from torch's.
+ * filled_out[T] (may be null) = ids with the mask positions replaced by the pick;
+ * pred_out[T]   (may be null) = the pick of every visited row (other rows are not written).
+ *
+ * ldm_remask_eligible + ldm_remask_apply replace RandomRemaskingStrategy.apply_remask
+ * (src/masking_strategy.py:160-198): pos_out[0..*count_out) = flat indices, ascending (the order
+ * of Tensor.nonzero()), of the positions that were masked in this step, are not bos/eos/pad and
+ * are not prompt positions (prompt may be null); then out = ids with out[pos[perm[j]]] = mask_id
+ * for j < k, where perm is the caller's permutation of 0..num_eligible-1 (torch.randperm in the
+ * reference, :189) and k = int(num_eligible * remask_ratio) (:182). */
+int ldm_sample_tokens(const void *logits, int dtype, int64_t T, int64_t V, int64_t ld, const int64_t *ids,
+                      int64_t mask_id, int all_rows, float temperature, uint64_t seed, uint64_t offset,
+                      int64_t *filled_out, int64_t *pred_out, void *stream);
+int ldm_remask_eligible(const int64_t *ids, const uint8_t *was_masked, const uint8_t *prompt, int64_t n,
+                        int64_t bos_id, int64_t eos_id, int64_t pad_id, int64_t *pos_out, int32_t *count_out,
+                        void *stream);
+int ldm_remask_apply(const int64_t *ids, int64_t n, const int64_t *pos, int64_t num_eligible,
+                     const int64_t *perm, int64_t k, int64_t mask_id, int64_t *out, void *stream);
+
 /* ---------------------------------------------------------------- fp32 softmax helpers
  * Used by the F32 attention path (materialised scores, as the reference does at
  * src/transformer.py:264-281).  Exposed for testing. */

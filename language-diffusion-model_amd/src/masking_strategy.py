@@ -1,9 +1,9 @@
-"""Forward-process masking on the fused HIP kernel (K1).
+"""Forward-process masking (K1) and reverse-process remasking on HIP kernels.
 
-Mirrors the forward half of the reference's ``src/masking_strategy.py``
-(``MaskingStrategy`` protocol :9-31, ``RandomMaskingStrategy`` :65-114,
-``create_masking_strategy`` :201-231).  The reverse-process remasking strategy
-is sampling/evaluation code and is not part of the training step.
+Mirrors the reference's ``src/masking_strategy.py``: ``MaskingStrategy`` /
+``RemaskingStrategy`` protocols (:9-62), ``RandomMaskingStrategy`` (:65-114),
+``RandomRemaskingStrategy`` (:117-198), ``create_masking_strategy`` (:201-231) and
+``create_remasking_strategy`` (:234-264).
 """
 
 from __future__ import annotations
@@ -20,6 +20,14 @@ class MaskingStrategy(Protocol):
     """Interface of a forward-process masking strategy (src/masking_strategy.py:9-31)."""
 
     def apply_random_mask(self, input_ids: Tensor, mask_prob: float) -> tuple[Tensor, Tensor]:
+        ...
+
+
+class RemaskingStrategy(Protocol):
+    """Interface of a reverse-process remasking strategy (src/masking_strategy.py:34-62)."""
+
+    def apply_remask(self, input_ids: Tensor, logits: Tensor, mask_indices: Tensor, remask_ratio: float,
+                     prompt_positions: Tensor | None = None) -> Tensor:
         ...
 
 
@@ -103,6 +111,55 @@ class RandomMaskingStrategy:
         return masked, mask, t_seq
 
 
+class RandomRemaskingStrategy:
+    """Puts the mask token back on a random ``int(num_eligible * remask_ratio)`` of the positions
+    that were filled in this step (src/masking_strategy.py:140-198).
+
+    Eligible = was masked this step, not BOS/EOS/PAD, not a prompt position; the choice is the
+    first ``k`` entries of ``torch.randperm(num_eligible, device=...)`` applied to the eligible
+    positions in row-major order -- the same generator call the reference makes (:189), so a
+    seeded run consumes the same stream.  ``logits`` is accepted and unused, as in the reference.
+    One host read of the eligible count per call (the reference has the same ``.item()``, :178)."""
+
+    def __init__(self, bos_token_id: int = 101, eos_token_id: int = 102, pad_token_id: int = 0,
+                 mask_token_id: int = 103):
+        self.bos_token_id = bos_token_id
+        self.eos_token_id = eos_token_id
+        self.pad_token_id = pad_token_id
+        self.mask_token_id = mask_token_id
+
+    def apply_remask(self, input_ids: Tensor, logits: Tensor | None, mask_indices: Tensor, remask_ratio: float,
+                     prompt_positions: Tensor | None = None) -> Tensor:
+        N.require_device(input_ids)
+        if input_ids.dtype != torch.int64:
+            raise TypeError(f"input_ids must be int64, got {input_ids.dtype}")
+        ids = input_ids.contiguous()
+        n = ids.numel()
+        out = torch.empty_like(ids)
+        if n == 0:
+            return out
+        dev = ids.device
+        was = mask_indices.to(device=dev, dtype=torch.bool).contiguous()
+        prompt = None
+        if prompt_positions is not None:
+            prompt = prompt_positions.to(device=dev, dtype=torch.bool).contiguous()
+        pos = torch.empty(n, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        lib, st = N.lib(), N.stream()
+        N.check(lib.ldm_remask_eligible(ids.data_ptr(), was.data_ptr(), N.ptr(prompt), n, self.bos_token_id,
+                                        self.eos_token_id, self.pad_token_id, pos.data_ptr(), count.data_ptr(), st),
+                "ldm_remask_eligible")
+        num_eligible = int(count.item())
+        k, perm = 0, None
+        if num_eligible > 0 and remask_ratio > 0:
+            k = int(num_eligible * remask_ratio)
+            if k > 0:
+                perm = torch.randperm(num_eligible, device=dev)
+        N.check(lib.ldm_remask_apply(ids.data_ptr(), n, pos.data_ptr(), num_eligible, N.ptr(perm), k,
+                                     self.mask_token_id, out.data_ptr(), st), "ldm_remask_apply")
+        return out
+
+
 def create_masking_strategy(strategy_name: Literal["random"], bos_token_id: int, eos_token_id: int,
                             pad_token_id: int, mask_token_id: int) -> MaskingStrategy:
     """Factory with the reference's signature and error (src/masking_strategy.py:201-231)."""
@@ -110,3 +167,12 @@ def create_masking_strategy(strategy_name: Literal["random"], bos_token_id: int,
         return RandomMaskingStrategy(bos_token_id=bos_token_id, eos_token_id=eos_token_id,
                                      pad_token_id=pad_token_id, mask_token_id=mask_token_id)
     raise ValueError(f"Unsupported masking strategy: {strategy_name}")
+
+
+def create_remasking_strategy(strategy_name: Literal["random"], bos_token_id: int, eos_token_id: int,
+                              pad_token_id: int, mask_token_id: int) -> RemaskingStrategy:
+    """Factory with the reference's signature and error (src/masking_strategy.py:234-264)."""
+    if strategy_name == "random":
+        return RandomRemaskingStrategy(bos_token_id=bos_token_id, eos_token_id=eos_token_id,
+                                       pad_token_id=pad_token_id, mask_token_id=mask_token_id)
+    raise ValueError(f"Unsupported remasking strategy: {strategy_name}")

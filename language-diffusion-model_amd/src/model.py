@@ -2,8 +2,9 @@
 
 Mirrors ``DiffusionLanguageModel.__init__`` / ``forward`` of the reference
 (src/model.py:22-72): draw t, mask, run the transformer, return
-``(logits, masked_input_ids, mask_indices)``.  ``generate`` / ``sample`` are
-reverse-process inference and are not part of this package.
+``(logits, masked_input_ids, mask_indices)``, and the reverse process
+``generate`` / ``sample`` (src/model.py:74-189) with the token choice and the
+remasking on HIP kernels.
 """
 
 from __future__ import annotations
@@ -14,6 +15,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from . import _native as N
 from . import ops
 
 
@@ -24,6 +26,9 @@ class DiffusionLanguageModel(nn.Module):
         self.tokenizer = tokenizer
         self.masking_strategy = masking_strategy
         self.remasking_strategy = remasking_strategy
+        self.sampling_rng = "philox"   # "torch": softmax + torch.multinomial, the reference's generator stream
+        self.sampling_seed = 0
+        self._sampling_calls = 0
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor | None = None,
                 t: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor]:
@@ -56,10 +61,81 @@ class DiffusionLanguageModel(nn.Module):
         return self.transformer.masked_token_loss(masked_input_ids, input_ids, self.tokenizer.mask_token_id,
                                                   attention_mask)
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError("reverse-process generation (src/model.py:74-106) is outside the "
-                                  "training-step scope of this package")
+    # ------------------------------------------------------------------ reverse process
+    def _pick_tokens(self, seq: Tensor, logits: Tensor, temperature: float) -> Tensor:
+        """seq with every mask position replaced by a token chosen from its logits row: argmax
+        for temperature 0, otherwise a draw from softmax(logits / temperature)
+        (src/model.py:93-105).  One kernel over the rows that hold a mask; no [T, V] softmax.
 
-    def sample(self, *args, **kwargs):
-        raise NotImplementedError("reverse-process sampling (src/model.py:108-189) is outside the "
-                                  "training-step scope of this package")
+        ``sampling_rng == "torch"`` keeps the reference's operators for the draw (softmax +
+        torch.multinomial, i.e. torch's generator stream); the default draws in the kernel from
+        Philox keyed by ``sampling_seed`` and a per-call counter."""
+        N.require_device(seq)
+        ids = seq.contiguous()
+        V = logits.shape[-1]
+        l2 = logits.reshape(-1, V)
+        if l2.stride(-1) != 1:
+            l2 = l2.contiguous()
+        if temperature > 0 and self.sampling_rng == "torch":
+            probs = torch.softmax(logits / temperature, dim=-1)
+            predictions = torch.multinomial(probs.reshape(-1, V), num_samples=1).reshape(ids.shape)
+            pos = ids == self.tokenizer.mask_token_id
+            out = ids.clone()
+            out[pos] = predictions[pos]
+            return out
+        out = torch.empty_like(ids)
+        offset = self._sampling_calls
+        self._sampling_calls += 1
+        N.check(N.lib().ldm_sample_tokens(l2.data_ptr(), N.dtype_code(l2.dtype), ids.numel(), V, l2.stride(0),
+                                          ids.data_ptr(), self.tokenizer.mask_token_id, 0, float(temperature),
+                                          self.sampling_seed, offset, out.data_ptr(), None, N.stream()),
+                "ldm_sample_tokens")
+        return out
+
+    def generate(self, input_ids: Tensor, temperature: float = 1.0) -> Tensor:
+        """One denoising pass: every mask token of ``input_ids`` is replaced by a prediction
+        (src/model.py:74-106; all positions attended, as there)."""
+        attention_mask = torch.ones_like(input_ids)
+        with torch.no_grad():
+            logits = self.transformer(input_ids=input_ids, attention_mask=attention_mask)
+            return self._pick_tokens(input_ids, logits, temperature)
+
+    def sample(self, prompt: Tensor | None = None, num_steps: int = 20, seq_length: int = 32,
+               temperature: float = 1.0) -> Tensor:
+        """Reverse diffusion (src/model.py:108-189): start from mask tokens (after the prompt, or
+        after a BOS), and ``num_steps`` times predict every masked position, then put the mask
+        back on a ``next_t / t`` share of the positions just filled, t = 1 - step/(num_steps-1).
+        Without a prompt the sequence is created on the transformer's device."""
+        mask_id = self.tokenizer.mask_token_id
+        if prompt is not None:
+            seq = prompt
+            batch_size = seq.size(0)
+            if seq.size(1) < seq_length:
+                padding = torch.full((batch_size, seq_length - seq.size(1)), mask_id, dtype=torch.long,
+                                     device=seq.device)
+                seq = torch.cat([seq, padding], dim=1)
+            else:
+                seq = seq[:, :seq_length]
+        else:
+            device = next(self.transformer.parameters()).device
+            seq = torch.full((1, seq_length), mask_id, dtype=torch.long, device=device)
+            seq[:, 0] = self.tokenizer.bos_token_id
+        seq = seq.contiguous()
+        attention_mask = torch.ones_like(seq)
+        prompt_positions = torch.zeros_like(seq, dtype=torch.bool)
+        if prompt is not None:
+            prompt_positions[:, :min(prompt.size(1), seq_length)] = True
+
+        for step in range(num_steps):
+            t = 1.0 - (step / (num_steps - 1))
+            next_t = 1.0 - ((step + 1) / (num_steps - 1)) if step < num_steps - 1 else 0.0
+            with torch.no_grad():
+                logits = self.transformer(input_ids=seq, attention_mask=attention_mask)
+                mask_positions = seq == mask_id
+                seq = self._pick_tokens(seq, logits, temperature)
+                if step < num_steps - 1:
+                    seq = self.remasking_strategy.apply_remask(input_ids=seq, logits=logits,
+                                                               mask_indices=mask_positions,
+                                                               remask_ratio=next_t / t,
+                                                               prompt_positions=prompt_positions)
+        return seq

@@ -36,6 +36,17 @@ def _load_oracle():
     return mod
 
 
+def _load_sampling_oracle():
+    """``oracle`` as a package (its modules import each other relatively) without putting the
+    repository root, which also holds a package called ``src``, on sys.path."""
+    spec = importlib.util.spec_from_file_location("oracle", os.path.join(HERE, "__init__.py"),
+                                                  submodule_search_locations=[HERE])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["oracle"] = pkg
+    spec.loader.exec_module(pkg)
+    return importlib.import_module("oracle.sampling_oracle")
+
+
 def _rel(a, b):
     a = a.double().flatten()
     b = b.double().flatten()
@@ -225,18 +236,118 @@ def build_loss(so, out_dir):
     print("[loss] oracle == reference on the reference-test fixture and a V=30522 case")
 
 
+def build_sampling(smp, so, out_dir):
+    """Reverse process: greedy generate(), apply_remask() and the greedy sample() loop of the
+    reference, with the permutations its torch.randperm calls returned recorded next to the
+    outputs (src/model.py:74-189, src/masking_strategy.py:140-198)."""
+    from src.masking_strategy import create_masking_strategy, create_remasking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+
+    V, d, H, L, Fd = 200, 32, 4, 2, 64
+    torch.manual_seed(21)
+    cfg = DiffusionTransformerConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd,
+                                     dropout=0.0, layer_norm_eps=1e-12, max_position_embeddings=512)
+    tr = DiffusionTransformer(cfg)
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103),
+                                   create_remasking_strategy("random", 101, 102, 0, 103))
+    model.eval()
+    params = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+    ocfg = so.OracleConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd, layer_norm_eps=1e-12)
+    out = {"cfg": np.array([V, d, H, L, Fd], dtype=np.int64)}
+    for k, v in params.items():
+        out["param/" + k] = v.numpy()
+
+    def min_gap(logits, rows):
+        top = torch.topk(logits.reshape(-1, V)[rows.reshape(-1)], 2, dim=-1).values
+        return float((top[:, 0] - top[:, 1]).min()) if top.numel() else 1.0
+
+    # (1) greedy generate
+    ids, _ = so.synthetic_batch(3, 12, V, seed=5, ragged=False, dirty=True)
+    g = torch.Generator().manual_seed(6)
+    holes = (torch.rand(ids.shape, generator=g) < 0.4) & (ids != 101) & (ids != 102) & (ids != 0)
+    ids = torch.where(holes, torch.full_like(ids, 103), ids)
+    with torch.no_grad():
+        gen = model.generate(ids, temperature=0)
+        logits = tr(input_ids=ids, attention_mask=torch.ones_like(ids))
+    assert min_gap(logits, ids == 103) > 1e-3
+    assert torch.equal(smp.pick_tokens(ids, logits, 103, 0.0), gen)
+    assert torch.equal(smp.pick_tokens(ids, so.transformer_forward(params, ocfg, ids, torch.ones_like(ids)), 103, 0.0), gen)
+    out.update(gen_ids=ids.numpy(), gen_logits=logits.numpy(), gen_out=gen.numpy())
+
+    # (2) remasking, permutations recorded from the generator stream the reference consumed
+    rs = model.remasking_strategy
+    cases = []
+    for j, (B, S, ratio, with_prompt, seed) in enumerate([(2, 16, 0.5, True, 3), (3, 33, 0.25, False, 4),
+                                                          (1, 8, 1.0, True, 5), (2, 16, 0.0, False, 6),
+                                                          (2, 9, 0.01, False, 7), (4, 64, 0.77, True, 8)]):
+        cur, _ = so.synthetic_batch(B, S, V, seed=seed, ragged=S > 9, dirty=True)
+        gg = torch.Generator().manual_seed(seed + 100)
+        was = torch.rand(cur.shape, generator=gg) < 0.6
+        prompt = None
+        if with_prompt:
+            prompt = torch.zeros_like(cur, dtype=torch.bool)
+            prompt[:, :3] = True
+        torch.manual_seed(seed)
+        res = rs.apply_remask(input_ids=cur, logits=None, mask_indices=was, remask_ratio=ratio, prompt_positions=prompt)
+        n = int(smp.eligible_positions(cur, was, prompt).numel())
+        torch.manual_seed(seed)
+        perm = torch.randperm(n) if (n > 0 and ratio > 0 and int(n * ratio) > 0) else torch.zeros(0, dtype=torch.long)
+        assert torch.equal(smp.apply_remask(cur, was, ratio, prompt, perm), res), j
+        out.update({f"rm{j}_ids": cur.numpy(), f"rm{j}_was": was.numpy(), f"rm{j}_ratio": np.array([ratio]),
+                    f"rm{j}_prompt": (prompt.numpy() if prompt is not None else np.zeros(0, dtype=bool)),
+                    f"rm{j}_perm": perm.numpy(), f"rm{j}_out": res.numpy()})
+        cases.append(j)
+    out["rm_cases"] = np.array(cases)
+
+    # (3) greedy sample loop; torch.randperm is wrapped for the duration to record what it returned
+    orig_randperm = torch.randperm
+    for j, (prompt, steps, length, seed) in enumerate([(ids[:2, :4].clone(), 6, 16, 33), (None, 5, 12, 34),
+                                                       (ids[:1, :12].clone(), 3, 8, 35)]):
+        rec = []
+
+        def recording(*a, **k):
+            p_ = orig_randperm(*a, **k)
+            rec.append(p_.clone())
+            return p_
+
+        torch.randperm = recording
+        try:
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                res = model.sample(prompt=prompt, num_steps=steps, seq_length=length, temperature=0)
+        finally:
+            torch.randperm = orig_randperm
+        ores = smp.sample_loop(params, ocfg, prompt, steps, length, rec, temperature=0.0)
+        assert torch.equal(ores, res), (j, ores, res)
+        out.update({f"sm{j}_prompt": (prompt.numpy() if prompt is not None else np.zeros((0, 0), dtype=np.int64)),
+                    f"sm{j}_steps": np.array([steps, length]), f"sm{j}_out": res.numpy(),
+                    f"sm{j}_nperm": np.array([len(rec)])})
+        for i, p_ in enumerate(rec):
+            out[f"sm{j}_perm{i}"] = p_.numpy()
+    np.savez_compressed(os.path.join(out_dir, "sampling.npz"), **out)
+    print("[sampling] oracle == reference on greedy generate, 6 remasking cases and 3 greedy sample loops")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only-sampling", action="store_true", help="rewrite sampling.npz only")
     args = ap.parse_args()
     so = _load_oracle()
     # the reference's package is called ``src``; import it from ITS checkout
     sys.path = [args.reference] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
     os.chdir(args.reference)
     os.makedirs(args.out, exist_ok=True)
+    smp = _load_sampling_oracle()
+    if "--only-sampling" in sys.argv:
+        build_sampling(smp, so, args.out)
+        return
     build_masking(so, args.out)
     build_loss(so, args.out)
+    build_sampling(smp, so, args.out)
     build_case(None, so, "c1_tiny", d=32, H=4, L=2, Fd=64, V=200, B=3, S=10, t=0.6, seed=42,
                ragged=True, dirty=True, out_dir=args.out)
     build_case(None, so, "hd96", d=192, H=2, L=1, Fd=128, V=300, B=2, S=48, t=0.5, seed=7,

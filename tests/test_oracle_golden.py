@@ -58,3 +58,39 @@ def test_step_golden(name):
                 assert float(np.abs(v.numpy() - ref).max()) < 1e-6
             else:
                 assert rel_err(v, ref) < 2e-6, (mode, k)
+
+
+def test_sampling_golden():
+    """Reverse process: greedy token choice, remasking with the recorded permutations and the
+    greedy sample loop reproduce what the reference returned (fixtures of oracle/make_golden.py)."""
+    from oracle import sampling_oracle as smp
+    g = load_golden("sampling.npz")
+    ids = torch.from_numpy(g["gen_ids"])
+    assert np.array_equal(smp.pick_tokens(ids, torch.from_numpy(g["gen_logits"]), 103, 0.0).numpy(), g["gen_out"])
+    for j in g["rm_cases"]:
+        prompt = torch.from_numpy(g[f"rm{j}_prompt"]) if g[f"rm{j}_prompt"].size else None
+        out = smp.apply_remask(torch.from_numpy(g[f"rm{j}_ids"]), torch.from_numpy(g[f"rm{j}_was"]),
+                               float(g[f"rm{j}_ratio"][0]), prompt, torch.from_numpy(g[f"rm{j}_perm"]))
+        assert np.array_equal(out.numpy(), g[f"rm{j}_out"]), j
+    V, d, H, L, Fd = [int(x) for x in g["cfg"]]
+    cfg = so.OracleConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd)
+    params = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    for j in range(3):
+        prompt = torch.from_numpy(g[f"sm{j}_prompt"]) if g[f"sm{j}_prompt"].size else None
+        steps, length = [int(x) for x in g[f"sm{j}_steps"]]
+        perms = [torch.from_numpy(g[f"sm{j}_perm{i}"]) for i in range(int(g[f"sm{j}_nperm"][0]))]
+        out = smp.sample_loop(params, cfg, prompt, steps, length, perms)
+        assert np.array_equal(out.numpy(), g[f"sm{j}_out"]), j
+
+
+def test_gumbel_choice_follows_softmax():
+    """The temperature > 0 choice of the sampling oracle (argmax of logits/T + Philox Gumbel
+    noise) is distributed as softmax(logits/T): chi-square against the exact probabilities."""
+    from oracle import sampling_oracle as smp
+    logits = torch.tensor([2.0, 1.0, 0.0, -1.0, 0.5, 0.5, -3.0])
+    rows = 20000
+    picks = torch.argmax(smp.token_scores(logits.repeat(rows, 1), 0.7, seed=11, offset=3), -1)
+    freq = torch.bincount(picks, minlength=7).double()
+    p = torch.softmax(logits.double() / 0.7, 0)
+    chi2 = float(((freq - rows * p) ** 2 / (rows * p)).sum())
+    assert chi2 < 30.0, chi2   # 6 degrees of freedom: P(chi2 > 30) ~ 4e-5
