@@ -626,6 +626,247 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
   }
 }
 
+// --------------------------------------------------------------------------- dQ, LDS-DMA tiles
+template <int DP>
+__global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
+  using T = AT<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, c = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, hd = a.hd;
+  const int64_t D = (int64_t)a.H * hd;
+  const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
+  const bf16_t *kb = qb + D, *vb = qb + 2 * D;
+  const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
+  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int qc = q < S ? q : S - 1;
+
+  TrAddr kta[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i) kta[i].init(i, lane);
+  TileDma kd, vd;
+  kd.init(kb, a.ld, hd, wave, lane);
+  vd.init(vb, a.ld, hd, wave, lane);
+  kd.issue(0, S, a.ld, smem, wave);
+  vd.issue(0, S, a.ld, smem + TILE2, wave);
+
+  bf8_t qf[T::NK], dof[T::NK];
+  const bf16_t *ob = a.o_in + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
+  float dsum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk) {
+    qf[kk] = global_frag(qb, a.ld, qc, true, kk, half, hd);
+    dof[kk] = global_frag(dob, a.ld_o, qc, true, kk, half, hd);
+    const bf8_t of = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
+  }
+  const float dlt = dsum + __shfl_xor(dsum, 32, 64);
+  const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
+  const float nlse = -a.lse_in[stat] * LOG2E;
+  if (half == 0 && q < S) a.delta[stat] = dlt;
+
+  f16_t dq[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  const int nt = (S + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * 64;
+    const char *Kt = smem + (t & 1) * 2 * TILE2;
+    const char *Vt = Kt + TILE2;
+    bool kok = (k0 + lane) < S;
+    if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
+    const unsigned long long vs = __ballot(kok) >> (4 * half);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) {
+      char *nb = smem + ((t + 1) & 1) * 2 * TILE2;
+      kd.issue(t + 1, S, a.ld, nb, wave);
+      vd.issue(t + 1, S, a.ld, nb + TILE2, wave);
+    }
+    const unsigned ko = lds_off(Kt);
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+      f16_t sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < T::NK; ++kk) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Kt, kbk * 32 + c, kk, half), qf[kk], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Vt, kbk * 32 + c, kk, half), dof[kk], dpacc, 0, 0, 0);
+      }
+      constexpr int NF = 2 * T::ND;
+      s4_t lo[NF], hi[NF];
+      const unsigned kbo = ko + kbk * 32 * PITCH2;
+      tr_issue2(kta[0], kbo, lo[0], hi[0]);
+      tr_issue2(kta[1 % T::ND], kbo + (1 / T::ND) * 16 * PITCH2, lo[1], hi[1]);
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = (vs >> (kbk * 32 + acc_row(r))) & 1ull;
+        const float p = ok ? fast_exp2(fmaf(sacc[r], LOG2E, nlse)) : 0.f;
+        ds[r] = p * (dpacc[r] - dlt);
+      }
+      const bf8_t dsf[2] = {pack8(ds), pack8(ds + 8)};
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) tr_issue2(kta[(f + 2) % T::ND], kbo + ((f + 2) / T::ND) * 16 * PITCH2, lo[f + 2], hi[f + 2]);
+        const bf8_t kf = (f + 2 < NF) ? tr_wait2<4>(lo[f], hi[f]) : (f + 1 < NF) ? tr_wait2<2>(lo[f], hi[f]) : tr_wait2<0>(lo[f], hi[f]);
+        dq[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf[f / T::ND], dq[f % T::ND], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (a.rope_cos) unrope_acc<DP>(dq, a.rope_scale, half, a.rope_cos + (int64_t)qc * (DP / 2), a.rope_sin + (int64_t)qc * (DP / 2));
+    if (aligned_to_dev(a.dqkv, 16))
+      store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.dqkv + ((int64_t)b * S + q0) * a.ld + (int64_t)head * hd, a.ld, dq,
+                         1.0f, lane, S - q0, hd);
+    else if (q < S)
+      store_rows<DP>(a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd, dq, 1.0f, half, hd);
+  }
+}
+
+// --------------------------------------------------------------------------- dK, dV, LDS-DMA tiles
+// Q and dO tiles and the two per-row statistics (lse, delta: 64 floats each, one 4-byte LDS-DMA
+// instruction of wave 0 / wave 1) land in one of two buffers; one barrier per tile.
+template <int DP>
+__global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
+  using T = AT<DP>;
+  constexpr int BUF = 2 * TILE2 + 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q image, dO image, lse[64], delta[64])
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, c = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, hd = a.hd;
+  const int64_t D = (int64_t)a.H * hd;
+  const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
+  const bf16_t *kb = qb + D, *vb = qb + 2 * D;
+  const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
+  const int key = blockIdx.x * 128 + wave * 32 + c;
+  bool key_ok = key < S;
+  if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
+  const int keyc = key < S ? key : S - 1;
+  const int64_t stat0 = ((int64_t)b * a.H + head) * S;
+
+  TrAddr ta[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i) ta[i].init(i, lane);
+  TileDma qd, gd;
+  qd.init(qb, a.ld, hd, wave, lane);
+  gd.init(dob, a.ld_o, hd, wave, lane);
+  auto issue = [&](int t, char *buf) {
+    qd.issue(t, S, a.ld, buf, wave);
+    gd.issue(t, S, a.ld_o, buf + TILE2, wave);
+    if (wave < 2) {   // rows past the end re-read the last row; their probabilities are zeroed below
+      const int qq = t * 64 + lane;
+      const float *src = (wave == 0 ? a.lse_in : a.delta) + stat0 + (qq < S ? qq : S - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(buf + 2 * TILE2 + wave * 256), 4, 0, 0);
+    }
+  };
+  issue(0, smem);
+
+  bf8_t kf[T::NK], vf[T::NK];
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk) {
+    kf[kk] = global_frag(kb, a.ld, keyc, key < S, kk, half, hd);
+    vf[kk] = global_frag(vb, a.ld, keyc, key < S, kk, half, hd);
+  }
+  f16_t dk[T::ND], dv[T::ND];
+#pragma unroll
+  for (int i = 0; i < T::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  const int nt = (S + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    const char *Qt = smem + (t & 1) * BUF;
+    const char *Gt = Qt + TILE2;
+    const float *lse_s = reinterpret_cast<const float *>(Qt + 2 * TILE2);
+    const float *dlt_s = lse_s + 64;
+    const int lim = S - t * 64;   // query rows of this tile that exist
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * BUF);
+    const unsigned qo = lds_off(Qt), go = lds_off(Gt);
+#pragma unroll
+    for (int qbk = 0; qbk < 2; ++qbk) {
+      f16_t sacc, dpacc;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 l4 = *reinterpret_cast<const float4 *>(lse_s + qbk * 32 + 8 * r4 + 4 * half);
+        const float4 d4 = *reinterpret_cast<const float4 *>(dlt_s + qbk * 32 + 8 * r4 + 4 * half);
+        sacc[4 * r4 + 0] = -l4.x * LOG2E; sacc[4 * r4 + 1] = -l4.y * LOG2E;
+        sacc[4 * r4 + 2] = -l4.z * LOG2E; sacc[4 * r4 + 3] = -l4.w * LOG2E;
+        dpacc[4 * r4 + 0] = -d4.x; dpacc[4 * r4 + 1] = -d4.y; dpacc[4 * r4 + 2] = -d4.z; dpacc[4 * r4 + 3] = -d4.w;
+      }
+      f16_t s0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < T::NK; ++kk) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Qt, qbk * 32 + c, kk, half), kf[kk], s0, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Gt, qbk * 32 + c, kk, half), vf[kk], dpacc, 0, 0, 0);
+      }
+      constexpr int NF = 2 * T::ND;
+      s4_t glo[NF], ghi[NF], qlo[NF], qhi[NF];
+      const unsigned gbo = go + qbk * 32 * PITCH2, qbo = qo + qbk * 32 * PITCH2;
+      tr_issue2(ta[0], gbo, glo[0], ghi[0]);
+      tr_issue2(ta[0], qbo, qlo[0], qhi[0]);
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = key_ok ? fast_exp2(fmaf(s0[r], LOG2E, sacc[r])) : 0.f;
+        p[r] = pr;
+        ds[r] = pr * dpacc[r];
+      }
+      if (lim < 64) {   // workgroup-uniform: the last, partial tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (qbk * 32 + acc_row(r) + 4 * half >= lim) { p[r] = 0.f; ds[r] = 0.f; }
+      }
+      const bf8_t pf[2] = {pack8(p), pack8(p + 8)}, dsf[2] = {pack8(ds), pack8(ds + 8)};
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + 1 < NF) {
+          const unsigned ro = ((f + 1) / T::ND) * 16 * PITCH2;
+          tr_issue2(ta[(f + 1) % T::ND], gbo + ro, glo[f + 1], ghi[f + 1]);
+          tr_issue2(ta[(f + 1) % T::ND], qbo + ro, qlo[f + 1], qhi[f + 1]);
+        }
+        // in flight after the issue: fragment pairs f and f+1 (four reads each)
+        const bf8_t gf = (f + 1 < NF) ? tr_wait2<6>(glo[f], ghi[f]) : tr_wait2<2>(glo[f], ghi[f]);
+        dv[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, pf[f / T::ND], dv[f % T::ND], 0, 0, 0);
+        const bf8_t qf2 = (f + 1 < NF) ? tr_wait2<4>(qlo[f], qhi[f]) : tr_wait2<0>(qlo[f], qhi[f]);
+        dk[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf2, dsf[f / T::ND], dk[f % T::ND], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int k0w = blockIdx.x * 128 + wave * 32;
+    if (a.rope_cos) unrope_acc<DP>(dk, 1.0f, half, a.rope_cos + (int64_t)keyc * (DP / 2), a.rope_sin + (int64_t)keyc * (DP / 2));
+    if (aligned_to_dev(a.dqkv, 16)) {
+      char *wl = smem + wave * 32 * T::RSTR;
+      bf16_t *row0 = a.dqkv + ((int64_t)b * S + k0w) * a.ld + (int64_t)head * hd;
+      store_tile_lds<DP>(wl, row0 + D, a.ld, dk, 1.0f, lane, S - k0w, hd);
+      store_tile_lds<DP>(wl, row0 + 2 * D, a.ld, dv, 1.0f, lane, S - k0w, hd);
+    } else if (key < S) {
+      bf16_t *row = a.dqkv + ((int64_t)b * S + key) * a.ld + (int64_t)head * hd;
+      store_rows<DP>(row + D, dk, 1.0f, half, hd);
+      store_rows<DP>(row + 2 * D, dv, 1.0f, half, hd);
+    }
+  }
+}
+
 // --------------------------------------------------------------------------- dQ
 template <int DP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
@@ -888,6 +1129,23 @@ bool attn_dma_enabled() {
 }
 
 template <int DP>
+int flash2_bwd_launch(const FArgs &a, hipStream_t s) {
+  constexpr int lds_dq = 4 * TILE2, lds_dkv = 2 * (2 * TILE2 + 512);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)flash2_bwd_dq_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute((const void *)flash2_bwd_dkv_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  hipLaunchKernelGGL(flash2_bwd_dq_k<DP>, grid, dim3(256), lds_dq, s, a);
+  LDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(flash2_bwd_dkv_k<DP>, grid, dim3(256), lds_dkv, s, a);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <int DP>
 int flash_bwd_launch(const FArgs &a, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
   hipLaunchKernelGGL(flash_bwd_dq_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
@@ -920,7 +1178,7 @@ int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
   if (!aligned_to(qkv, 16) || !aligned_to(o, 8)) return LDM_E_ALIGN;
   if (hd <= 32) return flash_fwd_launch<32>(a, s);
   if (hd <= 64) return flash_fwd_launch<64>(a, s);
-  if (attn_dma_enabled() && a.ld % 8 == 0) {
+  if (attn_dma_enabled() && a.ld % 8 == 0 && aligned_to(a.qkv, 16)) {
     if (hd == 96) return flash2_fwd_launch<96>(a, s);
     if (hd == 128) return flash2_fwd_launch<128>(a, s);
   }
@@ -943,6 +1201,10 @@ int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
   int rc = check(a);
   if (rc) return rc;
   if (!aligned_to(qkv, 16) || !aligned_to(dout, 16) || !aligned_to(o, 8) || !aligned_to(dqkv, 8)) return LDM_E_ALIGN;
+  if (attn_dma_enabled() && a.ld % 8 == 0 && a.ld_o % 8 == 0 && aligned_to(a.qkv, 16) && aligned_to(a.dout, 16)) {
+    if (hd == 96) return flash2_bwd_launch<96>(a, s);
+    if (hd == 128) return flash2_bwd_launch<128>(a, s);
+  }
   if (hd <= 32) return flash_bwd_launch<32>(a, s);
   if (hd <= 64) return flash_bwd_launch<64>(a, s);
   if (hd <= 96) return flash_bwd_launch<96>(a, s);
