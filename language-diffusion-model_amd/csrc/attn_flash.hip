@@ -61,6 +61,28 @@ struct FArgs {
 #endif
 
 __device__ __forceinline__ bool aligned_to_dev(const void *p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+// Workgroup -> (128-row block, head, batch).  The grid is one-dimensional and consecutive
+// workgroup ids go round-robin over the 8 XCDs, each with its own L2: the nblk workgroups that
+// stream the SAME K/V (or Q/dO) rows of one (batch, head) are therefore given ids that are 8
+// apart, so that they run on one XCD, back to back, and share those rows through its L2 instead
+// of fetching them from beyond L2 once per XCD.
+struct Blk { int blk, head, b; };
+__device__ __forceinline__ Blk decode_blk(const int S, const int H) {
+  const int nblk = (S + 127) / 128;
+  const int w = blockIdx.x, group = 8 * nblk;
+  int L = w;
+  if (w < (int)(gridDim.x / group) * group) {
+    const int j = w >> 3, x = w & 7;
+    L = ((j / nblk) * 8 + x) * nblk + j % nblk;
+  }
+  Blk r;
+  r.blk = L % nblk;
+  const int bh = L / nblk;
+  r.head = bh % H;
+  r.b = bh / H;
+  return r;
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // 64 rows x DP columns, rows >= S and columns >= hd zero-filled
@@ -233,12 +255,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
   char *Vt = smem + 64 * T::RSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, c = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
+  const Blk blk = decode_blk(a.S, a.H);
+  const int b = blk.b, head = blk.head;
   const int S = a.S, hd = a.hd;
   const int64_t D = (int64_t)a.H * hd;
   const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
-  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int q = blk.blk * 128 + wave * 32 + c;
 
 #ifdef LDM_ATTN_TIMING
   unsigned long long tk0;
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   if (q < S && half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
   {
-    const int q0 = blockIdx.x * 128 + wave * 32;   // the loop ended with a barrier: the K/V tiles are dead
+    const int q0 = blk.blk * 128 + wave * 32;   // the loop ended with a barrier: the K/V tiles are dead
     if (a.ld_o % 8 == 0 && aligned_to_dev(a.o, 16))
       store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.o + ((int64_t)b * S + q0) * a.ld_o + (int64_t)head * hd, a.ld_o,
                          oacc, 1.0f / ltot, lane, S - q0, hd);
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
       store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
   }
 #ifdef LDM_ATTN_TIMING
-  if (a.timing && tid == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) {
+  if (a.timing && tid == 0 && blockIdx.x == 8) {
     unsigned long long tk1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ASTAMP(tk1);
@@ -394,76 +417,69 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
 // =========================================================================== LDS-DMA variants
 // Head dims 96 and 128: the streamed 64-row tiles go global -> LDS by 16-byte LDS-DMA (no
 // register staging, no ds_write, one barrier per tile, two buffers).  An LDS-DMA instruction
-// writes 1 KiB of CONTIGUOUS LDS, so rows cannot be padded; instead every row has a 256-byte
-// pitch (16 chunks of 16 B, 12 or 16 of them used) and chunk c of row r sits at position
-// c ^ swz2(r): conflict-free both for the by-row reads (16 lanes = 16 rows, one chunk) and for
-// the transposing reads (32 lanes = 4 rows x 4 chunks).  The swizzle is applied to the SOURCE
-// address of each lane; lanes whose source chunk does not exist (c >= hd/8) are masked off.
-constexpr int PITCH2 = 256;
-constexpr int TILE2 = 64 * PITCH2;
+// writes 1 KiB of CONTIGUOUS LDS (lane l at +16 l), so rows cannot be padded: the row pitch is
+// exactly the row (192 B for head dim 96, 256 B for 128) and 16-byte chunk c of row r sits at
+// chunk position pos(c, r), an XOR swizzle applied to the SOURCE address of each lane:
+//   pitch 256: c ^ (((r & 3) << 2) | ((r >> 2) & 3))
+//   pitch 192: c ^ ((r >> 2) & 3)     (rows already step 48 banks; only the low chunk bits move)
+// Both are conflict-free for the by-row reads (16 lanes = 16 rows, one chunk) and for the
+// transposing reads (32 lanes = 4 rows x 4 chunks), and invariant under r += 16.
 __device__ __forceinline__ int swz2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+template <int DP>
+struct Lay {
+  static_assert(DP == 96 || DP == 128, "LDS-DMA tiles: head dim 96 or 128");
+  static constexpr int PITCH = DP * 2;
+  static constexpr int CPR = PITCH / 16;           // chunks per row
+  static constexpr int TILE = 64 * PITCH;          // bytes of a 64-row image
+  static constexpr int PW = TILE / 1024 / 4;       // LDS-DMA instructions per wave per image
+  static __device__ __forceinline__ int pos(int ch, int r) {
+    return DP == 96 ? (ch ^ ((r >> 2) & 3)) : (ch ^ swz2(r));
+  }
+};
 
 #define LDS_PTR2(p) ((__attribute__((address_space(3))) void *)(p))
 #define GLB_PTR2(p) ((const __attribute__((address_space(1))) void *)(p))
 
-// The 4 LDS-DMA pieces (4 rows x 256 B each) of a 64-row tile that one of the 4 waves issues.
-// Lanes whose chunk does not exist (head dim 96: chunks 12..15) fetch another chunk of the same
-// row instead of being masked off: what they write is never read, and the issue stays branch-free.
+// The PW LDS-DMA pieces (1 KiB each) of a 64-row image that one of the 4 waves issues.
+template <int DP>
 struct TileDma {
-  const bf16_t *p[4];   // source of this lane in tile 0, piece i
-  int64_t step;         // 64 rows
-  int rr;
-  __device__ __forceinline__ void init(const bf16_t *base, int64_t ld, int hd, int wave, int lane) {
+  using L = Lay<DP>;
+  const bf16_t *p[L::PW];   // source of this lane in tile 0, piece i
+  int row0[L::PW];          // its tile-relative row
+  int64_t step;             // 64 rows
+  __device__ __forceinline__ void init(const bf16_t *base, int64_t ld, int wave, int lane) {
     step = 64 * ld;
-    rr = lane >> 4;
-    const int pc = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 4 + rr;
-      int sc = pc ^ swz2(row);
-      if (sc * 8 >= hd) sc &= 3;
-      p[i] = base + (int64_t)row * ld + sc * 8;
+    for (int i = 0; i < L::PW; ++i) {
+      const int cidx = (wave * L::PW + i) * 64 + lane;   // chunk slot of this lane in the image
+      const int row = cidx / L::CPR, slot = cidx % L::CPR;
+      row0[i] = row;
+      p[i] = base + (int64_t)row * ld + L::pos(slot, row) * 8;   // pos() is its own inverse
     }
   }
-  // tile t -> image `img`; rows >= S re-read row S-1 (finite values; their scores are masked)
-  __device__ __forceinline__ void issue(int t, int S, int64_t ld, char *img, int wave) const {
+  // piece i of tile t -> image `img`; rows >= S re-read row S-1 (finite values; masked later)
+  __device__ __forceinline__ void issue_one(int i, int t, int S, int64_t ld, char *img, int wave) const {
     const int lim = S - 64 * t;
-    if (lim >= 64) {
+    const bf16_t *src = p[i] + (int64_t)t * step;
+    if (lim < 64) src -= (int64_t)(row0[i] >= lim ? row0[i] - (lim - 1) : 0) * ld;   // lim is wave-uniform
+    __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(img + (wave * L::PW + i) * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void issue(int t, int S, int64_t ld, char *img, int wave) const {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds(GLB_PTR2(p[i] + (int64_t)t * step), LDS_PTR2(img + (wave * 4 + i) * 1024),
-                                         16, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 4 + rr;
-        const bf16_t *src = p[i] + (int64_t)t * step - (int64_t)(row >= lim ? row - (lim - 1) : 0) * ld;
-        __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(img + (wave * 4 + i) * 1024), 16, 0, 0);
-      }
-    }
+    for (int i = 0; i < L::PW; ++i) issue_one(i, t, S, ld, img, wave);
   }
 };
 
+template <int DP>
 __device__ __forceinline__ bf8_t row_frag2(const char *tile, int row, int kk, int half) {
-  return *reinterpret_cast<const bf8_t *>(tile + row * PITCH2 + (((kk * 2 + half) ^ swz2(row)) << 4));
-}
-__device__ __forceinline__ bf8_t tr_frag2(const char *tile, int rbase, int dblk, int lane) {
-  const int half = lane >> 5, gg = (lane >> 4) & 1, i = lane & 15;
-  const int r0 = rbase + 4 * half + (i >> 2), r1 = r0 + 8;
-  const int d0 = dblk * 32 + 16 * gg + 4 * (i & 3);
-  const int ch = d0 >> 3, in = (d0 & 7) * 2;
-  const char *a0 = tile + r0 * PITCH2 + ((ch ^ swz2(r0)) << 4) + in;
-  const char *a1 = tile + r1 * PITCH2 + ((ch ^ swz2(r1)) << 4) + in;
-  s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0));
-  s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a1));
-  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf8_t, v);
+  return *reinterpret_cast<const bf8_t *>(tile + row * Lay<DP>::PITCH + (Lay<DP>::pos(kk * 2 + half, row) << 4));
 }
 
 // Transposing reads issued from inline asm: the compiler orders nothing around them (its own
 // transposing-read intrinsic makes it drain every LDS-DMA in flight first), so the caller waits
 // with tr_wait2 before it uses the registers.  `base` = per-lane byte address of (r0, dblk)
 // within an image; `off` = image + 16-row-block offset, the second read is 8 rows on.
+template <int DP>
 struct TrAddr {
   unsigned a0, a1;
   __device__ __forceinline__ void init(int dblk, int lane) {
@@ -471,11 +487,12 @@ struct TrAddr {
     const int r0 = 4 * half + (i >> 2), r1 = r0 + 8;
     const int d0 = dblk * 32 + 16 * gg + 4 * (i & 3);
     const int ch = d0 >> 3, in = (d0 & 7) * 2;
-    a0 = r0 * PITCH2 + ((ch ^ swz2(r0)) << 4) + in;
-    a1 = r1 * PITCH2 + ((ch ^ swz2(r1)) << 4) + in;
+    a0 = r0 * Lay<DP>::PITCH + (Lay<DP>::pos(ch, r0) << 4) + in;
+    a1 = r1 * Lay<DP>::PITCH + (Lay<DP>::pos(ch, r1) << 4) + in;
   }
 };
-__device__ __forceinline__ void tr_issue2(const TrAddr &ta, unsigned off, s4_t &lo, s4_t &hi) {
+template <int DP>
+__device__ __forceinline__ void tr_issue2(const TrAddr<DP> &ta, unsigned off, s4_t &lo, s4_t &hi) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ta.a0 + off));
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ta.a1 + off));
 }
@@ -496,21 +513,22 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
+  const Blk blk = decode_blk(a.S, a.H);
+  const int b = blk.b, head = blk.head;
   const int S = a.S, hd = a.hd;
   const int64_t D = (int64_t)a.H * hd;
   const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
-  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int q = blk.blk * 128 + wave * 32 + c;
 
-  TrAddr vta[T::ND];
+  TrAddr<DP> vta[T::ND];
 #pragma unroll
   for (int i = 0; i < T::ND; ++i) vta[i].init(i, lane);
-  TileDma kd, vd;
-  kd.init(kb, a.ld, hd, wave, lane);
-  vd.init(vb, a.ld, hd, wave, lane);
+  TileDma<DP> kd, vd;
+  kd.init(kb, a.ld, wave, lane);
+  vd.init(vb, a.ld, wave, lane);
   kd.issue(0, S, a.ld, smem, wave);
-  vd.issue(0, S, a.ld, smem + TILE2, wave);
+  vd.issue(0, S, a.ld, smem + Lay<DP>::TILE, wave);
 
   bf8_t qf[T::NK];
 #pragma unroll
@@ -523,24 +541,38 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
 
+#ifdef LDM_ATTN_TIMING
+  unsigned long long ta[6] = {0, 0, 0, 0, 0, 0}, tk0, tk1, tb = 0;
+  ASTAMP(tk0);
+#endif
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
+#ifdef LDM_ATTN_TIMING
+    unsigned long long s0, s1, s2, s3, s4;
+    ASTAMP(s0);
+#endif
     const int k0 = t * 64;
-    const char *Kt = smem + (t & 1) * 2 * TILE2;
-    const char *Vt = Kt + TILE2;
+    const char *Kt = smem + (t & 1) * 2 * Lay<DP>::TILE;
+    const char *Vt = Kt + Lay<DP>::TILE;
     bool kok = (k0 + lane) < S;
     if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
     const unsigned long long valid = __ballot(kok);
     // tile t has landed (this wave's pieces); after the barrier it is visible to all and every
     // wave is done with tile t-1, whose buffer the next tile's LDS-DMA then refills
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LDM_ATTN_TIMING
+    { unsigned long long sw; ASTAMP(sw); ta[4] += sw - s0; }
+#endif
     __syncthreads();
-    if (t + 1 < nt) {
-      char *nb = smem + ((t + 1) & 1) * 2 * TILE2;
-      kd.issue(t + 1, S, a.ld, nb, wave);
-      vd.issue(t + 1, S, a.ld, nb + TILE2, wave);
-    }
+#ifdef LDM_ATTN_TIMING
+    { unsigned long long sb; ASTAMP(sb); ta[5] += 0; tb += sb - s0; }
+#endif
+    // the next tile's LDS-DMA is issued one instruction at a time between the MFMAs of S: an
+    // issue that stalls on a full memory queue then overlaps matrix work already in flight
+    const bool more = t + 1 < nt;
+    char *nb = smem + ((t + 1) & 1) * 2 * Lay<DP>::TILE;
 
+    ASTAMP(s1);
     f16_t sacc[2];
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
@@ -550,13 +582,19 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
       constexpr int NF = 2 * T::NK, AHEAD = 2;
       bf8_t kf[NF];
 #pragma unroll
-      for (int f = 0; f < AHEAD; ++f) kf[f] = row_frag2(Kt, (f / T::NK) * 32 + c, f % T::NK, half);
+      for (int f = 0; f < AHEAD; ++f) kf[f] = row_frag2<DP>(Kt, (f / T::NK) * 32 + c, f % T::NK, half);
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        if (f + AHEAD < NF) kf[f + AHEAD] = row_frag2(Kt, ((f + AHEAD) / T::NK) * 32 + c, (f + AHEAD) % T::NK, half);
+        if (f + AHEAD < NF) kf[f + AHEAD] = row_frag2<DP>(Kt, ((f + AHEAD) / T::NK) * 32 + c, (f + AHEAD) % T::NK, half);
         sacc[f / T::NK] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f], qf[f % T::NK], sacc[f / T::NK], 0, 0, 0);
+        if ((f & 1) == 0 && f / 2 < 2 * Lay<DP>::PW && more) {
+          constexpr int PW = Lay<DP>::PW;
+          if (f / 2 < PW) kd.issue_one(f / 2, t + 1, S, a.ld, nb, wave);
+          else vd.issue_one(f / 2 - PW, t + 1, S, a.ld, nb + Lay<DP>::TILE, wave);
+        }
       }
     }
+    ASTAMP(s2);
     if (valid != ~0ull) {
       const unsigned long long vs = valid >> (4 * half);
 #pragma unroll
@@ -589,13 +627,14 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     for (int i = 0; i < T::ND; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    ASTAMP(s3);
     {
       constexpr int NF = 4 * T::ND;
       const unsigned vo = lds_off(Vt);
       s4_t lo[NF], hi[NF];
       bf8_t pf[4];
       tr_issue2(vta[0], vo, lo[0], hi[0]);
-      tr_issue2(vta[1 % T::ND], vo + (1 / T::ND) * 16 * PITCH2, lo[1], hi[1]);
+      tr_issue2(vta[1 % T::ND], vo + (1 / T::ND) * 16 * Lay<DP>::PITCH, lo[1], hi[1]);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         float tmp[8];
@@ -605,25 +644,37 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        if (f + 2 < NF) tr_issue2(vta[(f + 2) % T::ND], vo + ((f + 2) / T::ND) * 16 * PITCH2, lo[f + 2], hi[f + 2]);
+        if (f + 2 < NF) tr_issue2(vta[(f + 2) % T::ND], vo + ((f + 2) / T::ND) * 16 * Lay<DP>::PITCH, lo[f + 2], hi[f + 2]);
         // reads in flight after this issue: fragments f .. min(f+2, NF-1), two each
         const bf8_t vf = (f + 2 < NF) ? tr_wait2<4>(lo[f], hi[f]) : (f + 1 < NF) ? tr_wait2<2>(lo[f], hi[f]) : tr_wait2<0>(lo[f], hi[f]);
         oacc[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[f / T::ND], oacc[f % T::ND], 0, 0, 0);
       }
     }
+#ifdef LDM_ATTN_TIMING
+    ASTAMP(s4);
+    ta[0] += s1 - s0; ta[1] += s2 - s1; ta[2] += s3 - s2; ta[3] += s4 - s3; ta[5] += 1;
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // every wave is done with the tiles: the epilogue re-uses the LDS
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   if (q < S && half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
   {
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk.blk * 128 + wave * 32;
     if (a.ld_o % 8 == 0 && aligned_to_dev(a.o, 16))
       store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.o + ((int64_t)b * S + q0) * a.ld_o + (int64_t)head * hd, a.ld_o,
                          oacc, 1.0f / ltot, lane, S - q0, hd);
     else if (q < S)
       store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
   }
+#ifdef LDM_ATTN_TIMING
+  if (a.timing && tid == 0 && blockIdx.x == 8) {
+    ASTAMP(tk1);
+    for (int i = 0; i < 6; ++i) a.timing[i] = ta[i];
+    a.timing[6] = tk1 - tk0;
+  }
+  if (a.timing && lane == 0 && blockIdx.x == 8) { a.timing[8 + wave] = tb; a.timing[12 + wave] = ta[4]; }
+#endif
 }
 
 // --------------------------------------------------------------------------- dQ, LDS-DMA tiles
@@ -634,23 +685,24 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
+  const Blk blk = decode_blk(a.S, a.H);
+  const int b = blk.b, head = blk.head;
   const int S = a.S, hd = a.hd;
   const int64_t D = (int64_t)a.H * hd;
   const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int q = blk.blk * 128 + wave * 32 + c;
   const int qc = q < S ? q : S - 1;
 
-  TrAddr kta[T::ND];
+  TrAddr<DP> kta[T::ND];
 #pragma unroll
   for (int i = 0; i < T::ND; ++i) kta[i].init(i, lane);
-  TileDma kd, vd;
-  kd.init(kb, a.ld, hd, wave, lane);
-  vd.init(vb, a.ld, hd, wave, lane);
+  TileDma<DP> kd, vd;
+  kd.init(kb, a.ld, wave, lane);
+  vd.init(vb, a.ld, wave, lane);
   kd.issue(0, S, a.ld, smem, wave);
-  vd.issue(0, S, a.ld, smem + TILE2, wave);
+  vd.issue(0, S, a.ld, smem + Lay<DP>::TILE, wave);
 
   bf8_t qf[T::NK], dof[T::NK];
   const bf16_t *ob = a.o_in + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
@@ -677,18 +729,16 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
     const int k0 = t * 64;
-    const char *Kt = smem + (t & 1) * 2 * TILE2;
-    const char *Vt = Kt + TILE2;
+    const char *Kt = smem + (t & 1) * 2 * Lay<DP>::TILE;
+    const char *Vt = Kt + Lay<DP>::TILE;
     bool kok = (k0 + lane) < S;
     if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
     const unsigned long long vs = __ballot(kok) >> (4 * half);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < nt) {
-      char *nb = smem + ((t + 1) & 1) * 2 * TILE2;
-      kd.issue(t + 1, S, a.ld, nb, wave);
-      vd.issue(t + 1, S, a.ld, nb + TILE2, wave);
-    }
+    // the next tile's LDS-DMA goes out one instruction at a time between the first MFMAs
+    const bool more = t + 1 < nt;
+    char *nb = smem + ((t + 1) & 1) * 2 * Lay<DP>::TILE;
     const unsigned ko = lds_off(Kt);
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk) {
@@ -697,14 +747,23 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
       for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < T::NK; ++kk) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Kt, kbk * 32 + c, kk, half), qf[kk], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Vt, kbk * 32 + c, kk, half), dof[kk], dpacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Kt, kbk * 32 + c, kk, half), qf[kk], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Vt, kbk * 32 + c, kk, half), dof[kk], dpacc, 0, 0, 0);
+        if (kbk == 0 && kk < 2 * Lay<DP>::PW && more) {
+          constexpr int PW = Lay<DP>::PW;
+          if (kk < PW) kd.issue_one(kk, t + 1, S, a.ld, nb, wave);
+          else vd.issue_one(kk - PW, t + 1, S, a.ld, nb + Lay<DP>::TILE, wave);
+        }
       }
       constexpr int NF = 2 * T::ND;
       s4_t lo[NF], hi[NF];
-      const unsigned kbo = ko + kbk * 32 * PITCH2;
-      tr_issue2(kta[0], kbo, lo[0], hi[0]);
-      tr_issue2(kta[1 % T::ND], kbo + (1 / T::ND) * 16 * PITCH2, lo[1], hi[1]);
+      const unsigned kbo = ko + kbk * 32 * Lay<DP>::PITCH;
+      // all transposed K fragments of this key block are requested before the exponentials:
+      // the LDS round trips overlap that VALU work instead of the MFMA chain below
+      constexpr int AH = DP == 96 ? NF : 4;
+#pragma unroll
+      for (int f = 0; f < AH; ++f)
+        tr_issue2(kta[f % T::ND], kbo + (f / T::ND) * 16 * Lay<DP>::PITCH, lo[f], hi[f]);
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -715,8 +774,14 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
       const bf8_t dsf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        if (f + 2 < NF) tr_issue2(kta[(f + 2) % T::ND], kbo + ((f + 2) / T::ND) * 16 * PITCH2, lo[f + 2], hi[f + 2]);
-        const bf8_t kf = (f + 2 < NF) ? tr_wait2<4>(lo[f], hi[f]) : (f + 1 < NF) ? tr_wait2<2>(lo[f], hi[f]) : tr_wait2<0>(lo[f], hi[f]);
+        if (f + AH < NF) tr_issue2(kta[(f + AH) % T::ND], kbo + ((f + AH) / T::ND) * 16 * Lay<DP>::PITCH, lo[f + AH], hi[f + AH]);
+        // reads in flight now: fragments f .. min(f + AH, NF - 1), two each
+        constexpr int LAST = NF - 1;
+        const int ahead = (f + AH < NF ? f + AH : LAST) - f;
+        const bf8_t kf = ahead >= 7 ? tr_wait2<14>(lo[f], hi[f]) : ahead == 6 ? tr_wait2<12>(lo[f], hi[f])
+                       : ahead == 5 ? tr_wait2<10>(lo[f], hi[f]) : ahead == 4 ? tr_wait2<8>(lo[f], hi[f])
+                       : ahead == 3 ? tr_wait2<6>(lo[f], hi[f]) : ahead == 2 ? tr_wait2<4>(lo[f], hi[f])
+                       : ahead == 1 ? tr_wait2<2>(lo[f], hi[f]) : tr_wait2<0>(lo[f], hi[f]);
         dq[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf[f / T::ND], dq[f % T::ND], 0, 0, 0);
       }
     }
@@ -724,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk.blk * 128 + wave * 32;
     if (a.rope_cos) unrope_acc<DP>(dq, a.rope_scale, half, a.rope_cos + (int64_t)qc * (DP / 2), a.rope_sin + (int64_t)qc * (DP / 2));
     if (aligned_to_dev(a.dqkv, 16))
       store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.dqkv + ((int64_t)b * S + q0) * a.ld + (int64_t)head * hd, a.ld, dq,
@@ -740,39 +805,40 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
 template <int DP>
 __global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
   using T = AT<DP>;
-  constexpr int BUF = 2 * TILE2 + 512;
+  constexpr int BUF = 2 * Lay<DP>::TILE + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q image, dO image, lse[64], delta[64])
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
+  const Blk blk = decode_blk(a.S, a.H);
+  const int b = blk.b, head = blk.head;
   const int S = a.S, hd = a.hd;
   const int64_t D = (int64_t)a.H * hd;
   const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  const int key = blockIdx.x * 128 + wave * 32 + c;
+  const int key = blk.blk * 128 + wave * 32 + c;
   bool key_ok = key < S;
   if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
   const int keyc = key < S ? key : S - 1;
   const int64_t stat0 = ((int64_t)b * a.H + head) * S;
 
-  TrAddr ta[T::ND];
+  TrAddr<DP> ta[T::ND];
 #pragma unroll
   for (int i = 0; i < T::ND; ++i) ta[i].init(i, lane);
-  TileDma qd, gd;
-  qd.init(qb, a.ld, hd, wave, lane);
-  gd.init(dob, a.ld_o, hd, wave, lane);
-  auto issue = [&](int t, char *buf) {
-    qd.issue(t, S, a.ld, buf, wave);
-    gd.issue(t, S, a.ld_o, buf + TILE2, wave);
+  TileDma<DP> qd, gd;
+  qd.init(qb, a.ld, wave, lane);
+  gd.init(dob, a.ld_o, wave, lane);
+  auto issue_stats = [&](int t, char *buf) {
     if (wave < 2) {   // rows past the end re-read the last row; their probabilities are zeroed below
       const int qq = t * 64 + lane;
       const float *src = (wave == 0 ? a.lse_in : a.delta) + stat0 + (qq < S ? qq : S - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(buf + 2 * TILE2 + wave * 256), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(buf + 2 * Lay<DP>::TILE + wave * 256), 4, 0, 0);
     }
   };
-  issue(0, smem);
+  qd.issue(0, S, a.ld, smem, wave);
+  gd.issue(0, S, a.ld_o, smem + Lay<DP>::TILE, wave);
+  issue_stats(0, smem);
 
   bf8_t kf[T::NK], vf[T::NK];
 #pragma unroll
@@ -789,13 +855,16 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
     const char *Qt = smem + (t & 1) * BUF;
-    const char *Gt = Qt + TILE2;
-    const float *lse_s = reinterpret_cast<const float *>(Qt + 2 * TILE2);
+    const char *Gt = Qt + Lay<DP>::TILE;
+    const float *lse_s = reinterpret_cast<const float *>(Qt + 2 * Lay<DP>::TILE);
     const float *dlt_s = lse_s + 64;
     const int lim = S - t * 64;   // query rows of this tile that exist
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < nt) issue(t + 1, smem + ((t + 1) & 1) * BUF);
+    // next tile: the statistics now, the images one LDS-DMA instruction at a time between the first MFMAs
+    const bool more = t + 1 < nt;
+    char *nb = smem + ((t + 1) & 1) * BUF;
+    if (more) issue_stats(t + 1, nb);
     const unsigned qo = lds_off(Qt), go = lds_off(Gt);
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
@@ -813,12 +882,17 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
       for (int r = 0; r < 16; ++r) s0[r] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < T::NK; ++kk) {
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Qt, qbk * 32 + c, kk, half), kf[kk], s0, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2(Gt, qbk * 32 + c, kk, half), vf[kk], dpacc, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Qt, qbk * 32 + c, kk, half), kf[kk], s0, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Gt, qbk * 32 + c, kk, half), vf[kk], dpacc, 0, 0, 0);
+        if (qbk == 0 && kk < 2 * Lay<DP>::PW && more) {
+          constexpr int PW = Lay<DP>::PW;
+          if (kk < PW) qd.issue_one(kk, t + 1, S, a.ld, nb, wave);
+          else gd.issue_one(kk - PW, t + 1, S, a.ld_o, nb + Lay<DP>::TILE, wave);
+        }
       }
       constexpr int NF = 2 * T::ND;
       s4_t glo[NF], ghi[NF], qlo[NF], qhi[NF];
-      const unsigned gbo = go + qbk * 32 * PITCH2, qbo = qo + qbk * 32 * PITCH2;
+      const unsigned gbo = go + qbk * 32 * Lay<DP>::PITCH, qbo = qo + qbk * 32 * Lay<DP>::PITCH;
       tr_issue2(ta[0], gbo, glo[0], ghi[0]);
       tr_issue2(ta[0], qbo, qlo[0], qhi[0]);
       float p[16], ds[16];
@@ -837,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         if (f + 1 < NF) {
-          const unsigned ro = ((f + 1) / T::ND) * 16 * PITCH2;
+          const unsigned ro = ((f + 1) / T::ND) * 16 * Lay<DP>::PITCH;
           tr_issue2(ta[(f + 1) % T::ND], gbo + ro, glo[f + 1], ghi[f + 1]);
           tr_issue2(ta[(f + 1) % T::ND], qbo + ro, qlo[f + 1], qhi[f + 1]);
         }
@@ -852,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
-    const int k0w = blockIdx.x * 128 + wave * 32;
+    const int k0w = blk.blk * 128 + wave * 32;
     if (a.rope_cos) unrope_acc<DP>(dk, 1.0f, half, a.rope_cos + (int64_t)keyc * (DP / 2), a.rope_sin + (int64_t)keyc * (DP / 2));
     if (aligned_to_dev(a.dqkv, 16)) {
       char *wl = smem + wave * 32 * T::RSTR;
@@ -876,13 +950,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
   char *Vt = smem + 64 * T::RSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, c = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
+  const Blk blk = decode_blk(a.S, a.H);
+  const int b = blk.b, head = blk.head;
   const int S = a.S, hd = a.hd;
   const int64_t D = (int64_t)a.H * hd;
   const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int q = blk.blk * 128 + wave * 32 + c;
   const int qc = q < S ? q : S - 1;
 
   bf8_t qf[T::NK], dof[T::NK];
@@ -961,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
     }
   }
   {
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk.blk * 128 + wave * 32;
     if (a.rope_cos) unrope_acc<DP>(dq, a.rope_scale, half, a.rope_cos + (int64_t)qc * (DP / 2), a.rope_sin + (int64_t)qc * (DP / 2));
     if (aligned_to_dev(a.dqkv, 16))
       store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.dqkv + ((int64_t)b * S + q0) * a.ld + (int64_t)head * hd, a.ld, dq,
@@ -982,13 +1057,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
   float *dlt_s = lse_s + 64;                                         // [64] -delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, c = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
+  const Blk blk = decode_blk(a.S, a.H);
+  const int b = blk.b, head = blk.head;
   const int S = a.S, hd = a.hd;
   const int64_t D = (int64_t)a.H * hd;
   const bf16_t *qb = a.qkv + (int64_t)b * S * a.ld + (int64_t)head * hd;
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  const int key = blockIdx.x * 128 + wave * 32 + c;
+  const int key = blk.blk * 128 + wave * 32 + c;
   bool key_ok = key < S;
   if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
   const int keyc = key < S ? key : S - 1;
@@ -1079,7 +1155,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
     }
   }
   {
-    const int k0w = blockIdx.x * 128 + wave * 32;
+    const int k0w = blk.blk * 128 + wave * 32;
     if (a.rope_cos) unrope_acc<DP>(dk, 1.0f, half, a.rope_cos + (int64_t)keyc * (DP / 2), a.rope_sin + (int64_t)keyc * (DP / 2));
     if (aligned_to_dev(a.dqkv, 16)) {
       char *wl = smem + wave * 32 * T::RSTR;
@@ -1098,7 +1174,7 @@ template <int DP>
 int flash_fwd_launch(const FArgs &a, hipStream_t s) {
   size_t lds = 64 * AT<DP>::RSTR + 64 * AT<DP>::TSTR;
   if (lds < (size_t)128 * AT<DP>::RSTR) lds = (size_t)128 * AT<DP>::RSTR;   // the epilogue stages O through LDS
-  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
   hipLaunchKernelGGL(flash_fwd_k<DP>, grid, dim3(256), lds, s, a);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
@@ -1106,13 +1182,13 @@ int flash_fwd_launch(const FArgs &a, hipStream_t s) {
 
 template <int DP>
 int flash2_fwd_launch(const FArgs &a, hipStream_t s) {
-  constexpr int lds = 4 * TILE2;
+  constexpr int lds = 4 * Lay<DP>::TILE;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)flash2_fwd_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
   hipLaunchKernelGGL(flash2_fwd_k<DP>, grid, dim3(256), lds, s, a);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
@@ -1130,14 +1206,14 @@ bool attn_dma_enabled() {
 
 template <int DP>
 int flash2_bwd_launch(const FArgs &a, hipStream_t s) {
-  constexpr int lds_dq = 4 * TILE2, lds_dkv = 2 * (2 * TILE2 + 512);
+  constexpr int lds_dq = 4 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)flash2_bwd_dq_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
     (void)hipFuncSetAttribute((const void *)flash2_bwd_dkv_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
     attr_set = true;
   }
-  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
   hipLaunchKernelGGL(flash2_bwd_dq_k<DP>, grid, dim3(256), lds_dq, s, a);
   LDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(flash2_bwd_dkv_k<DP>, grid, dim3(256), lds_dkv, s, a);
@@ -1147,7 +1223,7 @@ int flash2_bwd_launch(const FArgs &a, hipStream_t s) {
 
 template <int DP>
 int flash_bwd_launch(const FArgs &a, hipStream_t s) {
-  dim3 grid((unsigned)ceil_div(a.S, 128), (unsigned)a.H, (unsigned)a.B);
+  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
   hipLaunchKernelGGL(flash_bwd_dq_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
   LDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(flash_bwd_dkv_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR + 512, s, a);
@@ -1159,7 +1235,7 @@ int check(const FArgs &a) {
   if (a.B <= 0 || a.H <= 0 || a.S <= 0 || a.hd <= 0) return LDM_E_BADARG;
   if (a.hd % 8 || a.hd > 128) return LDM_E_SHAPE;
   if (a.ld % 8 || a.ld_o % 8) return LDM_E_ALIGN;
-  if (a.B > 65535 || a.H > 65535) return LDM_E_SHAPE;
+  if (ceil_div(a.S, 128) * (int64_t)a.H * a.B > 0x7fffffff) return LDM_E_SHAPE;   // one-dimensional grid
   return LDM_OK;
 }
 

@@ -1,0 +1,32 @@
+"""Times the three attention kernels alone (default-model shape) with events; prints us per call."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from src import _native as N
+dev = torch.device("cuda:0")
+B, S, H, hd = (int(x) for x in os.environ.get("SHAPE", "128,512,8,96").split(","))
+D = H * hd
+torch.manual_seed(0)
+qkv = torch.randn(B * S, 3 * D, device=dev).bfloat16()
+go = torch.randn(B * S, D, device=dev).bfloat16()
+o = torch.empty(B * S, D, device=dev, dtype=torch.bfloat16)
+lib = N.lib()
+saved = torch.empty(lib.ldm_attn_saved_bytes(1, B, H, S, hd), dtype=torch.uint8, device=dev)
+dqkv = torch.empty_like(qkv)
+ws = torch.empty(lib.ldm_attn_bwd_ws_bytes(1, B, H, S, hd), dtype=torch.uint8, device=dev)
+def fwd():
+    N.check(lib.ldm_attn_fwd(1, qkv.data_ptr(), 3 * D, None, B, H, S, hd, o.data_ptr(), D, saved.data_ptr(), N.stream()), "fwd")
+def bwd():
+    N.check(lib.ldm_attn_bwd(1, qkv.data_ptr(), 3 * D, None, B, H, S, hd, o.data_ptr(), go.data_ptr(), D, saved.data_ptr(),
+                             dqkv.data_ptr(), ws.data_ptr(), N.stream()), "bwd")
+def timeit(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+fl = 4.0 * B * H * S * S * hd
+tf, tb = timeit(fwd), timeit(bwd)
+print(f"LDM_ATTN_DMA={os.environ.get('LDM_ATTN_DMA', '1')} fwd {tf:.1f} us ({fl / tf / 1e6:.0f} TF)  bwd {tb:.1f} us ({2.5 * fl / tb / 1e6:.0f} TF)")

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 dev = torch.device("cuda:0")
-buf = torch.zeros(8, dtype=torch.int64, device=dev)
+buf = torch.zeros(16, dtype=torch.int64, device=dev)
 os.environ["LDM_ATTN_TIMING_BUF"] = str(buf.data_ptr())
 os.environ["LDM_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                      "language-diffusion-model_amd", "lib", "libldm_hip_timing.so")
@@ -20,8 +20,12 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); run(); e1.record(); torch.cuda.synchronize()
 t = buf.cpu().double()
 n = t[5].item()
-names = ["issue next-tile loads", "S = K Q^T (12 MFMA)", "softmax", "O += V^T P (12 MFMA)", "barriers + tile store"]
+names = ["wait + barrier + issue next tile", "S = K Q^T (12 MFMA)", "softmax", "O += V^T P (12 MFMA)", "  of the first: vmcnt wait"]
+if os.environ.get("LDM_ATTN_DMA") == "0":
+    names = ["issue next-tile loads", "S = K Q^T (12 MFMA)", "softmax", "O += V^T P (12 MFMA)", "barriers + tile store"]
 print(f"fwd {e0.elapsed_time(e1) * 1e3:.1f} us (instrumented); per tile of one wave, cycles:")
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {t[i].item() / n:8.1f}")
-print(f"  total {t[:5].sum().item() / n:8.1f}  tiles {int(n)}; whole kernel for that wave {t[6].item():.0f} cycles; workgroups per slot {B * H * (S // 128) / 512:.0f}")
+print(f"  total {t[:4].sum().item() / n:8.1f}  tiles {int(n)}; whole kernel for that wave {t[6].item():.0f} cycles; workgroups per slot {B * H * (S // 128) / 512:.0f}")
+
+print("per wave, cycles per tile: until past the barrier", [round(x / n) for x in t[8:12].tolist()], " of which vmcnt wait", [round(x / n) for x in t[12:16].tolist()])
