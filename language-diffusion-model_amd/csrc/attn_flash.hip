@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
 
 // --------------------------------------------------------------------------- dQ, LDS-DMA tiles
 template <int DP>
-__global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
+__global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs a) {
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void flash2_bwd_dq_k(FArgs a) {
 // Q and dO tiles and the two per-row statistics (lse, delta: 64 floats each, one 4-byte LDS-DMA
 // instruction of wave 0 / wave 1) land in one of two buffers; one barrier per tile.
 template <int DP>
-__global__ __launch_bounds__(256, 2) void flash2_bwd_dkv_k(FArgs a) {
+__global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs a) {
   using T = AT<DP>;
   constexpr int BUF = 2 * Lay<DP>::TILE + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q image, dO image, lse[64], delta[64])
