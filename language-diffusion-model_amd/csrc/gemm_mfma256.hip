@@ -648,9 +648,20 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
   // Small outputs go to the 128x128 kernel: filling 256 CUs with 256x256 tiles needs so many
   // K splits that the float-atomic epilogue (~1.3 TB/s chip-wide) costs more than it saves.
   static const bool force = getenv("LDM_GEMM_TILE") && atoi(getenv("LDM_GEMM_TILE")) == 256;
-  int64_t splits = ntiles >= 200 ? 1 : 256 / ntiles;
-  if (splits > np_total / 8) splits = np_total / 8;              // >= 8 half-tiles per workgroup
-  if (splits < 1) splits = 1;
+  // K splits: each work item costs its half-tiles (~1.6k cycles each) plus an epilogue of float
+  // atomics (~16k cycles); the persistent workgroups run ceil(items / CUs) rounds of them.  The
+  // split count that minimises rounds x item cost evens out the last round (192 tiles on 256 CUs:
+  // 4 splits = exactly 3 rounds); a larger count must win by 3 % to be taken.
+  int64_t splits = 1;
+  {
+    const int64_t cus = num_cus();
+    const int64_t smax = np_total / 8 < 64 ? np_total / 8 : 64;   // >= 8 half-tiles per work item
+    double best = 0.0;
+    for (int64_t sp = 1; sp <= smax; ++sp) {
+      const double cost = (double)ceil_div(ntiles * sp, cus) * ((double)ceil_div(np_total, sp) * 1600.0 + 16000.0);
+      if (sp == 1 || cost < best * 0.97) { best = cost; splits = sp; }
+    }
+  }
   // measured crossover: with >= 20 tiles and >= 100 half-tiles per work item the persistent
   // 256-row kernel wins (861 vs 625 TFLOP/s at 2304x768x65536); below that the atomics dominate
   const bool worth = ntiles >= 200 || (ntiles >= 20 && np_total / splits >= 100);

@@ -3,7 +3,7 @@
 set -o pipefail
 mkdir -p gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { tail -5 gpurun_out/prof.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { tail -5 gpurun_out/prof.err; exit 1; }
 python - "$1" <<'PY'
 import csv, sys, re
 rows=list(csv.DictReader(open("gpurun_out/prof/run_kernel_stats.csv")))
