@@ -96,10 +96,17 @@ __global__ __launch_bounds__(1024) void ce_finish_k(const float *row_loss, CeArg
   __shared__ float sm_c[16];
   double l = 0.0;
   float c = 0.f;
-  for (int64_t r = threadIdx.x; r < a.T; r += 1024) {
-    if (row_active(a, r)) {
-      l += (double)row_loss[r];
-      c += 1.0f;
+  for (int64_t r0 = threadIdx.x; r0 < a.T; r0 += 8 * 1024) {
+    bool f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = r0 + j * 1024 < a.T && row_active(a, r0 + j * 1024);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = f[j] ? row_loss[r0 + j * 1024] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      l += (double)v[j];
+      c += f[j] ? 1.0f : 0.f;
     }
   }
 #pragma unroll
@@ -221,6 +228,44 @@ __global__ __launch_bounds__(1024) void ce_compact_k(CeArgs a, int *rows, int *c
   if (threadIdx.x == 0) count[0] = base;
 }
 
+// Multi-block compaction: block b owns rows [1024 b, 1024 b + 1024) and counts the participating
+// rows BEFORE its chunk itself (independent flag reads, eight in flight), so no block waits for
+// another; the last block also writes the total.  Same output as ce_compact_k.
+__global__ __launch_bounds__(1024) void ce_compact_mb_k(CeArgs a, int *rows, int *count) {
+  __shared__ int wsum[16];
+  __shared__ int wpre[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t start = (int64_t)blockIdx.x * 1024;
+  int mine = 0;
+  int64_t r = threadIdx.x;
+  for (; r + 7 * 1024 < start; r += 8 * 1024) {
+    bool f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = row_active(a, r + j * 1024);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine += f[j] ? 1 : 0;
+  }
+  for (; r < start; r += 1024) mine += row_active(a, r) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if (lane == 0) wpre[wid] = mine;
+  const int64_t rr = start + threadIdx.x;
+  const bool act = rr < a.T && row_active(a, rr);
+  const unsigned long long m = __ballot(act);
+  if (lane == 0) wsum[wid] = __popcll(m);
+  __syncthreads();
+  int base = 0, before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base += wpre[w];
+    const int c = wsum[w];
+    before += w < wid ? c : 0;
+    total += c;
+  }
+  if (act) rows[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (int)rr;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count[0] = base + total;
+}
+
 // Backward into the COMPACT layout: block i handles compact row i (source row rows[i]);
 // rows count .. roundup(count, 64) are zero-filled so that a 32/64-deep reduction over the
 // compact rows can run past the count; later rows are not touched.
@@ -263,6 +308,146 @@ __global__ __launch_bounds__(256) void ce_bwd_compact_k(const T *logits, CeArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-byte-vector forms.  A workgroup WALKS rows (blockIdx.x, blockIdx.x + gridDim.x, ...) instead
+// of one workgroup per row: rows that do not take part cost one flag read shared by 64 candidate
+// rows (one ballot), not a workgroup launch each.  Every thread keeps UNR row vectors in flight.
+constexpr int CE_UNR = 4;
+
+template <typename T>
+__device__ __forceinline__ void ce_row_lse8(const T *row, int64_t V, MS &acc) {
+  const int nv = (int)(V >> 3);
+  for (int i0 = threadIdx.x; i0 < nv; i0 += 256 * CE_UNR) {
+    Raw8<T> v[CE_UNR];
+#pragma unroll
+    for (int u = 0; u < CE_UNR; ++u)
+      if (i0 + u * 256 < nv) v[u].load(row + (int64_t)(i0 + u * 256) * 8);
+#pragma unroll
+    for (int u = 0; u < CE_UNR; ++u)
+      if (i0 + u * 256 < nv) {
+        float mx = v[u].get(0);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[u].get(j));
+        if (mx > acc.m) {
+          acc.s *= __expf(acc.m - mx);
+          acc.m = mx;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.s += __expf(v[u].get(j) - acc.m);
+      }
+  }
+  for (int64_t i = ((int64_t)nv << 3) + threadIdx.x; i < V; i += 256) ms_push(acc, Elt<T>::ld(row + i));
+}
+
+// The rows this workgroup looks at are blockIdx.x + k * gridDim.x; their flags are read 64 at a
+// time by wave 0 and shared through LDS as a bit mask.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_walk8_k(const T *logits, CeArgs a, float *row_lse,
+                                                      float *row_loss) {
+  __shared__ unsigned long long sm_mask;
+  __shared__ float sm_m[4], sm_s[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t G = gridDim.x;
+  for (int64_t k0 = 0; blockIdx.x + k0 * G < a.T; k0 += 64) {
+    if (wid == 0) {
+      const int64_t r = blockIdx.x + (k0 + lane) * G;
+      const unsigned long long m = __ballot(r < a.T && row_active(a, r));
+      if (lane == 0) sm_mask = m;
+    }
+    __syncthreads();
+    unsigned long long mask = sm_mask;
+    while (mask) {
+      const int bit = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int64_t r = blockIdx.x + (k0 + bit) * G;
+      const T *row = logits + r * a.ld;
+      MS acc{-INFINITY, 0.f};
+      ce_row_lse8<T>(row, a.V, acc);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        MS other{__shfl_xor(acc.m, o, 64), __shfl_xor(acc.s, o, 64)};
+        acc = ms_merge(acc, other);
+      }
+      if (lane == 0) {
+        sm_m[wid] = acc.m;
+        sm_s[wid] = acc.s;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        MS t{sm_m[0], sm_s[0]};
+        for (int w = 1; w < 4; ++w) t = ms_merge(t, MS{sm_m[w], sm_s[w]});
+        const float lse = t.m + logf(t.s);
+        const int64_t tgt = a.targets[r];
+        const float xt = (tgt >= 0 && tgt < a.V) ? Elt<T>::ld(row + tgt) : 0.f;
+        const float w = a.seq_weight ? a.seq_weight[r / a.seq] : 1.0f;
+        row_lse[r] = lse;
+        row_loss[r] = w * (lse - xt);
+      }
+      __syncthreads();   // sm_m / sm_s are free again
+    }
+    __syncthreads();     // everybody has read sm_mask
+  }
+}
+
+// dlogits of one row, 16-byte vectors: vector i of the output (ld_d elements, zero beyond V) comes
+// from vector i of the logits row and is written by the thread that read it (in-place safe).
+template <typename T>
+__device__ __forceinline__ void ce_row_grad8(const T *row, T *drow, int64_t V, int64_t ld_d, float lse, float coef,
+                                             int64_t tgt) {
+  const int nv_full = (int)(V >> 3);          // vectors entirely inside the row
+  const int nv_d = (int)(ld_d >> 3);
+  for (int i0 = threadIdx.x; i0 < nv_d; i0 += 256 * CE_UNR) {
+    Raw8<T> v[CE_UNR];
+#pragma unroll
+    for (int u = 0; u < CE_UNR; ++u)
+      if (i0 + u * 256 < nv_full) v[u].load(row + (int64_t)(i0 + u * 256) * 8);
+#pragma unroll
+    for (int u = 0; u < CE_UNR; ++u) {
+      const int i = i0 + u * 256;
+      if (i >= nv_d) break;
+      float o[8];
+      if (i < nv_full) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __expf(v[u].get(j) - lse) * coef;
+        const int64_t dt = tgt - (int64_t)i * 8;
+        if (dt >= 0 && dt < 8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j == dt) o[j] -= coef;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t c = (int64_t)i * 8 + j;
+          o[j] = c < V ? (__expf(Elt<T>::ld(row + c) - lse) - (c == tgt ? 1.0f : 0.f)) * coef : 0.f;
+        }
+      }
+      Raw8<T>::store(drow + (int64_t)i * 8, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_compact8_k(const T *logits, CeArgs a, const float *row_lse,
+                                                         const float *countf, const float *gout, const int *rows,
+                                                         const int *count, T *dl, int64_t ld_d) {
+  const int cnt = count[0];
+  const int64_t lim = (((int64_t)cnt + 63) / 64) * 64;
+  const float norm = a.norm_mode == 0 ? countf[0] : (float)a.T;
+  const float g0 = gout[0];
+  for (int64_t i = blockIdx.x; i < lim && i < a.T + 63; i += gridDim.x) {
+    T *drow = dl + i * ld_d;
+    if (i >= cnt) {
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int64_t c = threadIdx.x; c < (ld_d >> 3); c += 256) Raw8<T>::store(drow + c * 8, z);
+      continue;
+    }
+    const int64_t r = rows[i];
+    const float w = a.seq_weight ? a.seq_weight[r / a.seq] : 1.0f;
+    ce_row_grad8<T>(logits + r * a.ld, drow, a.V, ld_d, row_lse[r], g0 * w / norm, a.targets[r]);
+  }
+}
+
 }  // namespace
 
 static int ce_args(CeArgs &a, int64_t ld, int64_t T, int64_t V, int64_t seq, const int64_t *targets,
@@ -293,7 +478,14 @@ extern "C" int ldm_ce_fwd(const void *logits, int dtype, int64_t ld, int64_t T, 
     if (T > 0x7fffffff) return LDM_E_SHAPE;
     const size_t esz = dtype == LDM_F32 ? 4 : 2;
     const bool vec = aligned_to(logits, 4 * esz) && ((ld * esz) % (4 * esz) == 0);
-    if (dtype == LDM_F32) {
+    if (aligned_to(logits, 8 * esz) && ld % 8 == 0 && V >= 2048 && V < (1ll << 33) &&
+        (dtype == LDM_F32 || dtype == LDM_BF16)) {
+      const unsigned grid = (unsigned)(T < 2048 ? T : 2048);
+      if (dtype == LDM_F32)
+        hipLaunchKernelGGL(ce_fwd_walk8_k<float>, dim3(grid), dim3(256), 0, s, (const float *)logits, a, row_lse, row_tmp);
+      else
+        hipLaunchKernelGGL(ce_fwd_walk8_k<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, row_tmp);
+    } else if (dtype == LDM_F32) {
       if (vec) hipLaunchKernelGGL((ce_fwd_rows_k<float, true>), dim3((unsigned)T), dim3(256), 0, s, (const float *)logits, a, row_lse, row_tmp);
       else hipLaunchKernelGGL((ce_fwd_rows_k<float, false>), dim3((unsigned)T), dim3(256), 0, s, (const float *)logits, a, row_lse, row_tmp);
     } else if (dtype == LDM_BF16) {
@@ -344,7 +536,10 @@ extern "C" int ldm_ce_compact_rows(int64_t T, int64_t seq, const int64_t *masked
   CeArgs a{};
   a.T = T; a.V = 1; a.ld = 1; a.seq = seq > 0 ? seq : 1; a.masked_ids = masked_ids; a.mask_token_id = mask_token_id;
   a.mask_bool = mask_bool; a.att_valid = att_valid;
-  hipLaunchKernelGGL(ce_compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, rows, count);
+  if (T > 1024 && T <= (1 << 18))
+    hipLaunchKernelGGL(ce_compact_mb_k, dim3((unsigned)((T + 1023) / 1024)), dim3(1024), 0, (hipStream_t)stream, a, rows, count);
+  else
+    hipLaunchKernelGGL(ce_compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, rows, count);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }
@@ -364,6 +559,17 @@ extern "C" int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int
   a.ld = ld; a.T = T; a.V = V; a.seq = seq > 0 ? seq : 1; a.targets = targets; a.seq_weight = seq_weight;
   a.norm_mode = norm_mode;
   hipStream_t s = (hipStream_t)stream;
+  if (aligned_to(logits, 8 * esz) && ld % 8 == 0 && aligned_to(dlogits, 8 * esz) && ld_d % 8 == 0 && V >= 2048 &&
+      V < (1ll << 33) && (dtype == LDM_F32 || dtype == LDM_BF16)) {
+    const int64_t tp = ((T + 63) / 64) * 64;
+    const unsigned grid = (unsigned)(tp < 2048 ? tp : 2048);
+    if (dtype == LDM_F32)
+      hipLaunchKernelGGL(ce_bwd_compact8_k<float>, dim3(grid), dim3(256), 0, s, (const float *)logits, a, row_lse, count, gout, rows, count_i, (float *)dlogits, ld_d);
+    else
+      hipLaunchKernelGGL(ce_bwd_compact8_k<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, count, gout, rows, count_i, (bf16_t *)dlogits, ld_d);
+    LDM_CHECK_LAUNCH();
+    return LDM_OK;
+  }
   if (dtype == LDM_F32)
     hipLaunchKernelGGL(ce_bwd_compact_k<float>, dim3((unsigned)(((T + 63) / 64) * 64)), dim3(256), 0, s, (const float *)logits, a, row_lse, count, gout, rows, count_i, (float *)dlogits, ld_d);
   else if (dtype == LDM_BF16)

@@ -280,23 +280,31 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w
 }
 
 // out[c] = sum_p partial[p][c]   (deterministic second stage)
-// Block = 32 columns x 8 partial lanes; each lane strides over the partials, LDS joins them.
-__global__ __launch_bounds__(256) void reduce_partials_k(const float *partial, int64_t nparts, int64_t d,
-                                                         float *out) {
-  __shared__ float sm[8][33];
+// Block = 32 columns x 32 partial lanes (1024 threads); each lane strides over the partials with
+// eight loads in flight, LDS joins the 32 lanes in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_partials_k(const float *partial, int64_t nparts, int64_t d,
+                                                          float *out) {
+  __shared__ float sm[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + tx;
   float s = 0.f;
   if (c < d) {
-#pragma unroll 8
-    for (int64_t p = ty; p < nparts; p += 8) s += partial[p * d + c];
+    int64_t p = ty;
+    for (; p + 7 * 32 < nparts; p += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = partial[(p + j * 32) * d + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; p < nparts; p += 32) s += partial[p * d + c];
   }
   sm[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && c < d) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += sm[i][tx];
+    for (int i = 0; i < 32; ++i) t += sm[i][tx];
     out[c] = t;
   }
 }
@@ -337,6 +345,57 @@ __global__ __launch_bounds__(256) void rope_qk_k(T *qkv, int64_t rows, int64_t s
     }
     st4(p, oa);
     st4(p + half, ob);
+  }
+}
+
+// 8-pair form (hd/2 a multiple of 8): a thread rotates 8 consecutive elements with their partners
+// hd/2 further on, 16-byte accesses for bf16.  A workgroup walks groups of RG consecutive rows;
+// inside a group the (row, q|k, head, vector) items are spread flat over the threads.
+template <typename T, int RG>
+__global__ __launch_bounds__(256) void rope_qk8_k(T *__restrict__ qkv, int rows, int seq, int nhead, int hd,
+                                                  int64_t ld, const float *__restrict__ cos_t,
+                                                  const float *__restrict__ sin_t, float q_scale, int inverse) {
+  const int half = hd >> 1;
+  const unsigned vph = (unsigned)half >> 3;               // vectors per head half
+  const unsigned per_head_set = (unsigned)nhead * vph;    // items of the q (or k) heads of one row
+  const unsigned per_row = 2u * per_head_set;
+  const int ngroups = (rows + RG - 1) / RG;
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int row0 = g * RG;
+    const int nr = rows - row0 < RG ? rows - row0 : RG;
+    const unsigned items = (unsigned)nr * per_row;
+    for (unsigned it = threadIdx.x; it < items; it += 256) {
+      const unsigned lr = it / per_row;
+      unsigned rem = it - lr * per_row;
+      const unsigned which = rem >= per_head_set ? 1u : 0u;
+      rem -= which * per_head_set;
+      const unsigned h = rem / vph;
+      const unsigned i0 = (rem - h * vph) * 8u;
+      const int row = row0 + (int)lr;
+      const int pos = row % seq;
+      T *p = qkv + (int64_t)row * ld + (int64_t)which * nhead * hd + (int64_t)h * hd + i0;
+      Raw8<T> a, b;
+      a.load(p);
+      b.load(p + half);
+      const float *cp = cos_t + (int64_t)pos * half + i0, *sp = sin_t + (int64_t)pos * half + i0;
+      const f4 c0 = ld4(cp), c1 = ld4(cp + 4), s0 = ld4(sp), s1 = ld4(sp + 4);
+      const float sc = which == 0 ? q_scale : 1.0f;
+      float oa[8], ob[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = j < 4 ? c0.v[j] : c1.v[j - 4], sn = j < 4 ? s0.v[j] : s1.v[j - 4];
+        const float av = a.get(j), bv = b.get(j);
+        if (!inverse) {
+          oa[j] = (av * c - bv * sn) * sc;
+          ob[j] = (bv * c + av * sn) * sc;
+        } else {
+          oa[j] = (av * c + bv * sn) * sc;
+          ob[j] = (bv * c - av * sn) * sc;
+        }
+      }
+      Raw8<T>::store(p, oa);
+      Raw8<T>::store(p + half, ob);
+    }
   }
 }
 
@@ -413,6 +472,95 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const T *ag, const T *dh, in
     }
     st4(dag + r * 2 * F + c, da);
     st4(dag + r * 2 * F + F + c, dg);
+  }
+}
+
+// 8-element-vector forms (F % 8 == 0): one wave per row, 16-byte accesses for bf16.
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd8_k(const T *__restrict__ ag, int64_t rows, int F,
+                                                     T *__restrict__ h) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = F >> 3;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const T *ar = ag + r * 2 * F, *gr = ar + F;
+    T *hr = h + r * F;
+    for (int v0 = lane; v0 < nvec; v0 += 128) {
+      const int v1 = v0 + 64;
+      const bool two = v1 < nvec;
+      Raw8<T> a0, g0, a1, g1;
+      a0.load(ar + v0 * 8);
+      g0.load(gr + v0 * 8);
+      if (two) {
+        a1.load(ar + v1 * 8);
+        g1.load(gr + v1 * 8);
+      }
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = g0.get(j);
+        const float sg = 1.0f / (1.0f + __expf(-g));
+        o[j] = a0.get(j) * (g * sg);
+      }
+      Raw8<T>::store(hr + v0 * 8, o);
+      if (two) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = g1.get(j);
+          const float sg = 1.0f / (1.0f + __expf(-g));
+          o[j] = a1.get(j) * (g * sg);
+        }
+        Raw8<T>::store(hr + v1 * 8, o);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd8_k(const T *__restrict__ ag, const T *__restrict__ dh,
+                                                     int64_t rows, int F, T *__restrict__ dag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = F >> 3;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const T *ar = ag + r * 2 * F, *gr = ar + F, *dr = dh + r * F;
+    T *oa = dag + r * 2 * F, *og = oa + F;
+    for (int v0 = lane; v0 < nvec; v0 += 128) {
+      const int v1 = v0 + 64;
+      const bool two = v1 < nvec;
+      Raw8<T> a0, g0, d0, a1, g1, d1;
+      a0.load(ar + v0 * 8);
+      g0.load(gr + v0 * 8);
+      d0.load(dr + v0 * 8);
+      if (two) {
+        a1.load(ar + v1 * 8);
+        g1.load(gr + v1 * 8);
+        d1.load(dr + v1 * 8);
+      }
+      float da[8], dg[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = g0.get(j), d = d0.get(j);
+        const float sg = 1.0f / (1.0f + __expf(-g));
+        da[j] = d * (g * sg);
+        dg[j] = d * a0.get(j) * sg * (1.0f + g * (1.0f - sg));
+      }
+      Raw8<T>::store(oa + v0 * 8, da);
+      Raw8<T>::store(og + v0 * 8, dg);
+      if (two) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = g1.get(j), d = d1.get(j);
+          const float sg = 1.0f / (1.0f + __expf(-g));
+          da[j] = d * (g * sg);
+          dg[j] = d * a1.get(j) * sg * (1.0f + g * (1.0f - sg));
+        }
+        Raw8<T>::store(oa + v1 * 8, da);
+        Raw8<T>::store(og + v1 * 8, dg);
+      }
+    }
   }
 }
 
@@ -618,7 +766,7 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
     }
 #undef RMS_B8
     LDM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(256), 0, s, dw_partial,
+    hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(1024), 0, s, dw_partial,
                        (int64_t)grid, d, dw);
     LDM_CHECK_LAUNCH();
     return LDM_OK;
@@ -637,7 +785,7 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
   }
 #undef RMS_B
   LDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(256), 0, s, dw_partial,
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(1024), 0, s, dw_partial,
                      (int64_t)grid, d, dw);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
@@ -674,7 +822,15 @@ extern "C" int ldm_rope_qk(void *qkv, int dtype, int64_t batch, int64_t seq, int
   const bool vec = (half % 4 == 0) && (ld % 4 == 0) && aligned_to(qkv, 16) && aligned_to(cos_t, 16) &&
                    aligned_to(sin_t, 16) && ((half * esz) % (4 * esz) == 0);
   if (dtype != LDM_F32 && dtype != LDM_BF16) return LDM_E_DTYPE;
-  if (vec) {
+  if (vec && half % 8 == 0 && ld % 8 == 0 && (nhead * hd) % 8 == 0 && rows < (1 << 30) && seq < (1 << 30) &&
+      2 * nhead * (half / 8) <= (1 << 20)) {
+    constexpr int RG = 8;
+    const unsigned grid = stream_grid(ceil_div(rows, RG), 1);
+    if (dtype == LDM_F32)
+      hipLaunchKernelGGL((rope_qk8_k<float, RG>), dim3(grid), dim3(256), 0, s, (float *)qkv, (int)rows, (int)seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+    else
+      hipLaunchKernelGGL((rope_qk8_k<bf16_t, RG>), dim3(grid), dim3(256), 0, s, (bf16_t *)qkv, (int)rows, (int)seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+  } else if (vec) {
     const unsigned grid = stream_grid(rows * 2 * nhead * (half / 4), 256);
     if (dtype == LDM_F32)
       hipLaunchKernelGGL(rope_qk_k<float>, dim3(grid), dim3(256), 0, s, (float *)qkv, rows, seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
@@ -698,6 +854,15 @@ extern "C" int ldm_swiglu_fwd(const void *ag, int64_t T, int64_t F, int dtype, v
   if (F % 4) return LDM_E_SHAPE;
   if (!aligned_to(ag, 16) || !aligned_to(h, 16)) return LDM_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (F % 8 == 0 && F < (1 << 28) && (dtype == LDM_F32 || dtype == LDM_BF16)) {
+    const unsigned g8 = stream_grid(T, 4);
+    if (dtype == LDM_F32)
+      hipLaunchKernelGGL(swiglu_fwd8_k<float>, dim3(g8), dim3(256), 0, s, (const float *)ag, T, (int)F, (float *)h);
+    else
+      hipLaunchKernelGGL(swiglu_fwd8_k<bf16_t>, dim3(g8), dim3(256), 0, s, (const bf16_t *)ag, T, (int)F, (bf16_t *)h);
+    LDM_CHECK_LAUNCH();
+    return LDM_OK;
+  }
   const unsigned grid = stream_grid(T * (F / 4), 256);
   if (dtype == LDM_F32)
     hipLaunchKernelGGL(swiglu_fwd_k<float>, dim3(grid), dim3(256), 0, s, (const float *)ag, T, F, (float *)h);
@@ -717,6 +882,15 @@ extern "C" int ldm_swiglu_bwd(const void *ag, const void *dh, int64_t T, int64_t
   if (F % 4) return LDM_E_SHAPE;
   if (!aligned_to(ag, 16) || !aligned_to(dh, 16) || !aligned_to(dag, 16)) return LDM_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (F % 8 == 0 && F < (1 << 28) && (dtype == LDM_F32 || dtype == LDM_BF16)) {
+    const unsigned g8 = stream_grid(T, 4);
+    if (dtype == LDM_F32)
+      hipLaunchKernelGGL(swiglu_bwd8_k<float>, dim3(g8), dim3(256), 0, s, (const float *)ag, (const float *)dh, T, (int)F, (float *)dag);
+    else
+      hipLaunchKernelGGL(swiglu_bwd8_k<bf16_t>, dim3(g8), dim3(256), 0, s, (const bf16_t *)ag, (const bf16_t *)dh, T, (int)F, (bf16_t *)dag);
+    LDM_CHECK_LAUNCH();
+    return LDM_OK;
+  }
   const unsigned grid = stream_grid(T * (F / 4), 256);
   if (dtype == LDM_F32)
     hipLaunchKernelGGL(swiglu_bwd_k<float>, dim3(grid), dim3(256), 0, s, (const float *)ag, (const float *)dh, T, F, (float *)dag);
@@ -785,7 +959,7 @@ static int colsum_impl(const void *X, int dtype, int64_t M, int64_t N, int64_t l
   else
     return LDM_E_DTYPE;
   LDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, s, ws, slices, N, out);
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(N, 32)), dim3(1024), 0, s, ws, slices, N, out);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }

@@ -30,3 +30,17 @@ def timeit(fn, reps=20):
 fl = 4.0 * B * H * S * S * hd
 tf, tb = timeit(fwd), timeit(bwd)
 print(f"LDM_ATTN_DMA={os.environ.get('LDM_ATTN_DMA', '1')} fwd {tf:.1f} us ({fl / tf / 1e6:.0f} TF)  bwd {tb:.1f} us ({2.5 * fl / tb / 1e6:.0f} TF)")
+if os.environ.get("TORCH"):     # calibration only: torch's scaled_dot_product_attention on the same shape
+    import torch.nn.functional as Fn
+    q, k, v = (torch.randn(B, H, S, hd, device=dev).bfloat16().requires_grad_(True) for _ in range(3))
+    g4 = torch.randn(B, H, S, hd, device=dev).bfloat16()
+    def sf():
+        return Fn.scaled_dot_product_attention(q, k, v)
+    out = sf()
+    def sb():
+        out.backward(g4, retain_graph=True)
+    try:
+        t1, t2 = timeit(sf), timeit(sb)
+        print(f"torch sdpa fwd {t1:.1f} us ({fl / t1 / 1e6:.0f} TF)  bwd {t2:.1f} us ({2.5 * fl / t2 / 1e6:.0f} TF)")
+    except Exception as e:  # noqa: BLE001
+        print("torch sdpa failed:", e)

@@ -39,4 +39,17 @@ for name, ta, tb, M, Nn, K in shapes:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{name:4s} M={M:6d} N={Nn:6d} K={K:6d}  {ms*1e3:9.1f} us  {2.0*M*Nn*K/ms/1e9:8.1f} TF", flush=True)
+    line = f"{name:4s} M={M:6d} N={Nn:6d} K={K:6d}  {ms*1e3:9.1f} us  {2.0*M*Nn*K/ms/1e9:8.1f} TF"
+    if os.environ.get("TORCH"):     # calibration only: the vendor library GEMM of the same shape (bf16 output)
+        at = a.t() if ta else a
+        bt = b.t() if tb else b
+        for _ in range(3):
+            torch.matmul(at, bt)
+        e0.record()
+        for _ in range(reps):
+            torch.matmul(at, bt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / reps
+        line += f"   | torch.matmul {ms2*1e3:9.1f} us  {2.0*M*Nn*K/ms2/1e9:8.1f} TF"
+    print(line, flush=True)
