@@ -662,9 +662,11 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
       if (sp == 1 || cost < best * 0.97) { best = cost; splits = sp; }
     }
   }
-  // measured crossover: with >= 20 tiles and >= 100 half-tiles per work item the persistent
-  // 256-row kernel wins (861 vs 625 TFLOP/s at 2304x768x65536); below that the atomics dominate
-  const bool worth = ntiles >= 200 || (ntiles >= 20 && np_total / splits >= 100);
+  // measured: with >= 9 tiles and >= 64 half-tiles per work item the persistent 256-row kernel
+  // wins (861 vs 625 TFLOP/s at 2304x768x65536; equal to the 128x128 kernel at 768x768x65536 on
+  // cache-warm operands, ~15 % faster inside the training step, where the operands come from HBM
+  // and the smaller tile streams twice the bytes per flop); below that the atomics dominate
+  const bool worth = ntiles >= 200 || (ntiles >= 9 && np_total / splits >= 64);
   if (!worth && !force) return LDM_E_SHAPE;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = (int)splits;
   g.rowsum = rowsum;
