@@ -235,6 +235,22 @@ int ldm_gemm_acc_kdyn(int transA, int transB, int64_t M, int64_t N, int64_t K, c
 int ldm_colsum_rows_dyn(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
                         const int32_t *m_dev, void *stream);
 
+/* Loss and its gradient in ONE pass over compact logit rows (training step, LM head computed on the
+ * participating rows only): masked_cross_entropy_loss (src/loss.py:12-28) and the backward of
+ * F.cross_entropy (src/loss.py:22 under autograd) together.  Rows 0..*count-1 of logits
+ * [rows_alloc, ld] all take part, targets[i] is the label of compact row i.  Each row is read once:
+ *   row_tmp[i] = logsumexp(row) - row[target],   row := (softmax(row) - onehot(target)) / norm
+ * with norm = *count (norm_mode 0) or norm_T (norm_mode 1); columns V..ld-1 are written as zero and
+ * rows *count..roundup(*count, 64)-1 are zeroed.  loss_out[0] = sum_i row_tmp[i] / norm (0 when
+ * *count == 0), count_out[0] = *count.  The gradient left in logits is for an upstream gradient of
+ * 1; ldm_scale_rows_dev applies another one (x[i, :ncols] *= *scale for i < *count; a launch that
+ * returns at once when *scale == 1).  V up to 131072; 16-byte aligned rows (ld % 8 == 0). */
+int ldm_ce_fwd_grad(void *logits, int dtype, int64_t ld, int64_t rows_alloc, int64_t V,
+                    const int64_t *targets, const int32_t *count, int norm_mode, float norm_T,
+                    float *row_lse, float *row_tmp, float *loss_out, float *count_out, void *stream);
+int ldm_scale_rows_dev(void *x, int dtype, int64_t ld, int64_t rows_alloc, int64_t ncols,
+                       const int32_t *count, const float *scale, void *stream);
+
 /* ---------------------------------------------------------------- reverse process: token selection
  * ldm_sample_tokens replaces what DiffusionLanguageModel.generate / sample do with the logits
  * (src/model.py:93-105 and :167-177): for every row whose id is mask_id (all_rows != 0: for

@@ -448,6 +448,157 @@ __global__ __launch_bounds__(256) void ce_bwd_compact8_k(const T *logits, CeArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward AND gradient in one pass over compact rows [0, *count): a row is read once into
+// registers (NV 16-byte vectors per thread), its log-sum-exp and loss term come from the
+// registers, and (softmax - onehot) / norm is written back over the row -- one read and one
+// write of the logits instead of read (forward) + read + write (backward).  Rows
+// *count .. roundup(*count, 64) are zeroed (the weight-gradient GEMM reduces over them).
+template <int BT>
+__device__ __forceinline__ float block_reduce(float v, float *sm, bool is_max) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  float r = sm[0];
+#pragma unroll
+  for (int w = 1; w < BT / 64; ++w) r = is_max ? fmaxf(r, sm[w]) : r + sm[w];
+  __syncthreads();
+  return r;
+}
+
+template <typename T, int BT, int NV>
+__global__ __launch_bounds__(BT) void ce_fwd_grad_k(T *logits, int64_t ld, int64_t V, int64_t rows_alloc,
+                                                    const int64_t *targets, const int *count, float norm_T,
+                                                    int norm_mode, float *row_lse, float *row_loss) {
+  __shared__ float sm[BT / 64];
+  __shared__ float sm_xt;
+  const int cnt = count[0];
+  int64_t lim = (((int64_t)cnt + 63) / 64) * 64;
+  if (lim > rows_alloc) lim = rows_alloc;
+  const float norm = norm_mode == 0 ? (float)cnt : norm_T;
+  const float inv = norm > 0.f ? 1.0f / norm : 0.f;
+  const int nv_d = (int)(ld >> 3);                 // vectors per stored row
+  const int nv = (int)((V + 7) >> 3);              // vectors holding logits (the last may be partial)
+  const int nu = (nv + BT - 1) / BT;               // vector rounds of the block (uniform)
+  const int vlast = (int)(V >> 3), jlast = (int)(V & 7);   // the partial vector and its first invalid element
+  for (int64_t i = blockIdx.x; i < lim; i += gridDim.x) {
+    T *row = logits + i * ld;
+    if (i >= cnt) {
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int c = threadIdx.x; c < nv_d; c += BT) Raw8<T>::store(row + (int64_t)c * 8, z);
+      continue;
+    }
+    // columns >= V (and vectors past the row) hold -infinity in registers: every pass then runs
+    // the same code on every vector (exp(-inf) = 0 is also what their gradient must be)
+    Raw8<T> v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      if (u < nu) {
+        const int c = threadIdx.x + u * BT;
+        v[u].load(row + (c < nv ? c : 0) * 8);
+        if (c >= vlast) v[u].neg_inf_from(c == vlast ? jlast : 0);
+      }
+    }
+    const int64_t tgt = targets[i];
+    const int tvec = (tgt >= 0 && tgt < V) ? (int)(tgt >> 3) : -1, tj = (int)(tgt & 7);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (u < nu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[u].get(j));
+      }
+    mx = block_reduce<BT>(mx, sm, true);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u].pin();
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (u < nu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += __expf(v[u].get(j) - mx);
+        if ((int)threadIdx.x + u * BT == tvec) {   // one thread of the block
+          float xt = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (tj == j) xt = v[u].get(j);
+          sm_xt = xt;
+        }
+      }
+    sum = block_reduce<BT>(sum, sm, false);      // its barriers also publish sm_xt
+    const float lse = mx + logf(sum);
+    if (threadIdx.x == 0) {
+      row_lse[i] = lse;
+      row_loss[i] = lse - (tvec >= 0 ? sm_xt : 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u].pin();
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (u < nu) {
+        const int c = threadIdx.x + u * BT;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __expf(v[u].get(j) - lse) * inv;
+        if (c == tvec) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (tj == j) o[j] -= inv;
+        }
+        if (c < nv) Raw8<T>::store(row + (int64_t)c * 8, o);
+      }
+    __syncthreads();   // sm_xt is free for the next row
+  }
+}
+
+// loss = sum_{i < count} row_loss[i] / norm (deterministic order), count_out = count
+__global__ __launch_bounds__(1024) void ce_finish_compact_k(const float *row_loss, const int *count, float norm_T,
+                                                            int norm_mode, float *loss_out, float *count_out) {
+  __shared__ double sm_l[16];
+  const int cnt = count[0];
+  double l = 0.0;
+  for (int r0 = threadIdx.x; r0 < cnt; r0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = r0 + j * 1024 < cnt ? row_loss[r0 + j * 1024] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l += (double)v[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+  if ((threadIdx.x & 63) == 0) sm_l[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tl = 0.0;
+    for (int w = 0; w < 16; ++w) tl += sm_l[w];
+    const float norm = norm_mode == 0 ? (float)cnt : norm_T;
+    loss_out[0] = (cnt > 0 && norm > 0.f) ? (float)(tl / (double)norm) : 0.f;
+    count_out[0] = (float)cnt;
+  }
+}
+
+// x[i, 0..ncols) *= *scale for i < *count -- nothing is touched when *scale == 1
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_dev_k(T *x, int64_t ld, int64_t ncols, const int *count,
+                                                        const float *scale) {
+  const float sc = scale[0];
+  if (sc == 1.0f) return;
+  const int cnt = count[0];
+  const int nv = (int)(ncols >> 3);
+  for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    T *row = x + i * ld;
+    for (int c = threadIdx.x; c < nv; c += 256) {
+      Raw8<T> v;
+      v.load(row + (int64_t)c * 8);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = v.get(j) * sc;
+      Raw8<T>::store(row + (int64_t)c * 8, o);
+    }
+  }
+}
+
 }  // namespace
 
 static int ce_args(CeArgs &a, int64_t ld, int64_t T, int64_t V, int64_t seq, const int64_t *targets,
@@ -574,6 +725,67 @@ extern "C" int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int
     hipLaunchKernelGGL(ce_bwd_compact_k<float>, dim3((unsigned)(((T + 63) / 64) * 64)), dim3(256), 0, s, (const float *)logits, a, row_lse, count, gout, rows, count_i, (float *)dlogits, ld_d);
   else if (dtype == LDM_BF16)
     hipLaunchKernelGGL(ce_bwd_compact_k<bf16_t>, dim3((unsigned)(((T + 63) / 64) * 64)), dim3(256), 0, s, (const bf16_t *)logits, a, row_lse, count, gout, rows, count_i, (bf16_t *)dlogits, ld_d);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <typename T>
+static int ce_fwd_grad_launch(void *logits, int64_t ld, int64_t rows_alloc, int64_t V, const int64_t *targets,
+                              const int32_t *count, float norm_T, int norm_mode, float *row_lse, float *row_tmp,
+                              hipStream_t s) {
+  const int64_t nv = (V + 7) / 8;
+  if (nv <= 256 * 16) {
+    const unsigned grid = (unsigned)(rows_alloc < 2048 ? rows_alloc : 2048);
+    hipLaunchKernelGGL((ce_fwd_grad_k<T, 256, 16>), dim3(grid), dim3(256), 0, s, (T *)logits, ld, V, rows_alloc, targets,
+                       count, norm_T, norm_mode, row_lse, row_tmp);
+  } else if (nv <= 1024 * 16) {
+    const unsigned grid = (unsigned)(rows_alloc < 512 ? rows_alloc : 512);
+    hipLaunchKernelGGL((ce_fwd_grad_k<T, 1024, 16>), dim3(grid), dim3(1024), 0, s, (T *)logits, ld, V, rows_alloc,
+                       targets, count, norm_T, norm_mode, row_lse, row_tmp);
+  } else {
+    return LDM_E_SHAPE;
+  }
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_ce_fwd_grad(void *logits, int dtype, int64_t ld, int64_t rows_alloc, int64_t V,
+                               const int64_t *targets, const int32_t *count, int norm_mode, float norm_T,
+                               float *row_lse, float *row_tmp, float *loss_out, float *count_out, void *stream) {
+  if (rows_alloc < 0 || V <= 0 || ld < V) return LDM_E_BADARG;
+  if (!targets || !count || !loss_out || !count_out) return LDM_E_BADARG;
+  if (norm_mode != 0 && norm_mode != 1) return LDM_E_BADARG;
+  if (rows_alloc > 0x7fffffff) return LDM_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (rows_alloc > 0) {
+    if (!logits || !row_lse || !row_tmp) return LDM_E_BADARG;
+    const size_t esz = dtype == LDM_F32 ? 4 : 2;
+    if (!aligned_to(logits, 8 * esz) || ld % 8) return LDM_E_ALIGN;
+    int rc;
+    if (dtype == LDM_F32) rc = ce_fwd_grad_launch<float>(logits, ld, rows_alloc, V, targets, count, norm_T, norm_mode, row_lse, row_tmp, s);
+    else if (dtype == LDM_BF16) rc = ce_fwd_grad_launch<bf16_t>(logits, ld, rows_alloc, V, targets, count, norm_T, norm_mode, row_lse, row_tmp, s);
+    else return LDM_E_DTYPE;
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(ce_finish_compact_k, dim3(1), dim3(1024), 0, s, row_tmp, count, norm_T, norm_mode, loss_out, count_out);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+extern "C" int ldm_scale_rows_dev(void *x, int dtype, int64_t ld, int64_t rows_alloc, int64_t ncols,
+                                  const int32_t *count, const float *scale, void *stream) {
+  if (rows_alloc < 0 || ncols < 0 || ld < ncols) return LDM_E_BADARG;
+  if (rows_alloc == 0 || ncols == 0) return LDM_OK;
+  if (!x || !count || !scale) return LDM_E_BADARG;
+  const size_t esz = dtype == LDM_F32 ? 4 : 2;
+  if (!aligned_to(x, 8 * esz) || ld % 8 || ncols % 8) return LDM_E_ALIGN;
+  const unsigned grid = (unsigned)(rows_alloc < 2048 ? rows_alloc : 2048);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(scale_rows_dev_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)x, ld, ncols, count, scale);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(scale_rows_dev_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t *)x, ld, ncols, count, scale);
   else
     return LDM_E_DTYPE;
   LDM_CHECK_LAUNCH();

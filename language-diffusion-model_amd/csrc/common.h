@@ -66,6 +66,21 @@ template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
   uint4 u;
   __device__ __forceinline__ void load(const bf16_t *p) { u = *reinterpret_cast<const uint4 *>(p); }
+  // opaque use: values derived from the registers before this point are not kept alive past it
+  // (a multi-pass kernel re-derives them from the 16 stored bytes instead of holding 8 floats)
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
+  // elements j >= j0 become -infinity (j0 >= 8: nothing changes; j0 <= 0: all of them)
+  __device__ __forceinline__ void neg_inf_from(int j0) {
+    unsigned *w = &u.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned x = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
+      if (2 * k >= j0) x = (x & 0xffff0000u) | 0x0000ff80u;
+      if (2 * k + 1 >= j0) x = (x & 0x0000ffffu) | 0xff800000u;
+      if (k == 0) u.x = x; else if (k == 1) u.y = x; else if (k == 2) u.z = x; else u.w = x;
+    }
+    (void)w;
+  }
   __device__ __forceinline__ float get(int j) const {
     const unsigned w = j < 2 ? u.x : j < 4 ? u.y : j < 6 ? u.z : u.w;
     return (j & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
@@ -84,6 +99,18 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ void load(const float *p) {
     a = *reinterpret_cast<const float4 *>(p);
     b = *reinterpret_cast<const float4 *>(p + 4);
+  }
+  __device__ __forceinline__ void pin() {}
+  __device__ __forceinline__ void neg_inf_from(int j0) {
+    const float ninf = -__builtin_inff();
+    if (0 >= j0) a.x = ninf;
+    if (1 >= j0) a.y = ninf;
+    if (2 >= j0) a.z = ninf;
+    if (3 >= j0) a.w = ninf;
+    if (4 >= j0) b.x = ninf;
+    if (5 >= j0) b.y = ninf;
+    if (6 >= j0) b.z = ninf;
+    if (7 >= j0) b.w = ninf;
   }
   __device__ __forceinline__ float get(int j) const {
     return j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : j == 3 ? a.w : j == 4 ? b.x : j == 5 ? b.y : j == 6 ? b.z : b.w;

@@ -8,6 +8,7 @@ provides device memory, streams and the autograd tape.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import Tensor
@@ -579,6 +580,9 @@ class _MaskedCE(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------
 FUSED_HEAD_LOSS = True   # set False to always materialise the full [T, V] logits in the training step
+# loss and d(loss)/d(logits) in ONE pass over the compact logits when a backward will follow
+# (False: log-sum-exp pass in forward, softmax-minus-onehot pass in backward)
+FUSED_CE_GRAD = os.environ.get("LDM_FUSED_CE", "1") != "0"
 FUSED_HEAD_STATS = {"used": 0}
 
 
@@ -602,7 +606,7 @@ class _HeadMaskedCE(torch.autograd.Function):
     the dense computation's: the skipped rows contribute exact zeros there."""
 
     @staticmethod
-    def forward(ctx, x2, pack: PackedWeights, targets, masked_ids, att_valid, mask_token_id, *params):
+    def forward(ctx, x2, pack: PackedWeights, targets, masked_ids, att_valid, mask_token_id, want_grad, *params):
         N.require_device(x2)
         lib = N.lib()
         st = N.stream()
@@ -622,7 +626,6 @@ class _HeadMaskedCE(torch.autograd.Function):
         N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), cnt.data_ptr(), T, k,
                                     xc.data_ptr(), st), "ldm_gather_rows")
         tgc = tg[rows.long()]                                       # entries past the count repeat row 0: unused
-        valid = torch.arange(T, dtype=torch.int32, device=dev) < cnt  # compact row i exists
         lc = torch.empty(Tp, n_pad, dtype=torch.bfloat16, device=dev)
         ev = GEMM_EVENTS.get("head.fwd") if GEMM_EVENTS is not None else None
         if ev is not None:
@@ -636,9 +639,17 @@ class _HeadMaskedCE(torch.autograd.Function):
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         tmp = torch.empty(T, dtype=torch.float32, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)
-        N.check(lib.ldm_ce_fwd(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
-                               valid.view(torch.uint8).data_ptr(), None, None, 0, lse.data_ptr(), tmp.data_ptr(),
-                               out[0:1].data_ptr(), out[1:2].data_ptr(), st), "ldm_ce_fwd")
+        ctx.grad_ready = bool(want_grad and FUSED_CE_GRAD and pack.n <= 131072)
+        if ctx.grad_ready:
+            # one read + one write of the compact logits: they leave this call as d(loss)/d(logits)
+            N.check(lib.ldm_ce_fwd_grad(lc.data_ptr(), N.BF16, n_pad, Tp, pack.n, tgc.data_ptr(), cnt.data_ptr(), 0, 0.0,
+                                        lse.data_ptr(), tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), st),
+                    "ldm_ce_fwd_grad")
+        else:
+            valid = torch.arange(T, dtype=torch.int32, device=dev) < cnt  # compact row i exists
+            N.check(lib.ldm_ce_fwd(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
+                                   valid.view(torch.uint8).data_ptr(), None, None, 0, lse.data_ptr(), tmp.data_ptr(),
+                                   out[0:1].data_ptr(), out[1:2].data_ptr(), st), "ldm_ce_fwd")
         ctx.pack = pack
         ctx.save_for_backward(xc, w, lc, tgc, lse, out, rows, cnt)
         ctx.dims = (T, k)
@@ -660,11 +671,16 @@ class _HeadMaskedCE(torch.autograd.Function):
         n_pad = pack.n_pad
         dev = xc.device
         g = gout.reshape(1).float().contiguous()
-        ident = torch.arange(T, dtype=torch.int32, device=dev)
-        # dlogits over the logits, in place (each element is read and written by the same thread)
-        N.check(lib.ldm_ce_bwd_compact(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
-                                       lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(), ident.data_ptr(),
-                                       cnt.data_ptr(), lc.data_ptr(), n_pad, st), "ldm_ce_bwd_compact")
+        if ctx.grad_ready:
+            # the forward left the gradient for an upstream gradient of 1: a no-op launch in that case
+            N.check(lib.ldm_scale_rows_dev(lc.data_ptr(), N.BF16, n_pad, lc.shape[0], n_pad, cnt.data_ptr(),
+                                           g.data_ptr(), st), "ldm_scale_rows_dev")
+        else:
+            ident = torch.arange(T, dtype=torch.int32, device=dev)
+            # dlogits over the logits, in place (each element is read and written by the same thread)
+            N.check(lib.ldm_ce_bwd_compact(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
+                                           lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(), ident.data_ptr(),
+                                           cnt.data_ptr(), lc.data_ptr(), n_pad, st), "ldm_ce_bwd_compact")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
@@ -685,14 +701,16 @@ class _HeadMaskedCE(torch.autograd.Function):
             grads_w.append(dw[off:off + ne])
             grads_b.append(db[off:off + ne])
             off += ne
-        return (dx, None, None, None, None, None, *grads_w, *grads_b)
+        return (dx, None, None, None, None, None, None, *grads_w, *grads_b)
 
 
 def head_masked_ce(x: Tensor, pack: PackedWeights, targets: Tensor, masked_ids: Tensor, mask_token_id: int,
                    att_valid: Tensor | None = None) -> Tensor:
     """variational_lower_bound_loss(linear(x), ...) computed on the participating rows only."""
     x2 = _rows2d(x)
-    return _HeadMaskedCE.apply(x2, pack, targets, masked_ids, att_valid, mask_token_id, *pack.weights, *pack.biases)
+    want_grad = torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in pack.weights + pack.biases))
+    return _HeadMaskedCE.apply(x2, pack, targets, masked_ids, att_valid, mask_token_id, want_grad, *pack.weights,
+                               *pack.biases)
 
 
 def _padded_strides(shape, ld):

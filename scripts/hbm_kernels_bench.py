@@ -133,3 +133,14 @@ os.makedirs("gpurun_out", exist_ok=True)
 json.dump({"peak_GB/s": PEAK, "shapes": {"B": B, "S": S, "d": d, "F": F, "V": V, "ce_rows": ROWS},
            "method": "algorithmic bytes / event-timed average of 20 launches", "kernels": results},
           open("gpurun_out/hbm_kernels.json", "w"), indent=1)
+
+# ---- one-pass loss + gradient over compact rows (read once, written once)
+logits2 = torch.randn(ROWS, Vp, device=dev).to(bf)
+cnt_i = torch.tensor([ROWS], dtype=torch.int32, device=dev)
+report("ce_fwd_grad (one pass)", 2 * ROWS * V * 2 + 8 * ROWS,
+       lambda: N.check(lib.ldm_ce_fwd_grad(logits2.data_ptr(), 1, Vp, ROWS, V, tg.data_ptr(), cnt_i.data_ptr(), 0, 0.0,
+                                           lse.data_ptr(), tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), st()),
+                       "cefg"))
+json.dump({"peak_GB/s": PEAK, "shapes": {"B": B, "S": S, "d": d, "F": F, "V": V, "ce_rows": ROWS},
+           "method": "algorithmic bytes / event-timed average of 20 launches", "kernels": results},
+          open("gpurun_out/hbm_kernels.json", "w"), indent=1)

@@ -436,3 +436,53 @@ def test_gemm_rows_dyn_many_tiles(dev):
     want = torch.zeros(M, N, dtype=torch.float64, device=dev)
     want[perm.long()] = a[:cnt_v].double() @ w.double().t()
     assert rel_err(c2.float(), want) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,V,count", [(128, 30522, 100), (64, 2051, 64), (256, 32000, 0), (64, 40000, 37),
+                                          (64, 126464, 3)])
+def test_ce_fwd_grad_one_pass(dev, dtype, rows, V, count):
+    """ldm_ce_fwd_grad (loss and gradient from one read of each compact row) against
+    F.cross_entropy + autograd on the same rows (src/loss.py:22), incl. a vocabulary that is not a
+    multiple of 8, zero participating rows, the zeroed rounding rows, and the 1024-thread form."""
+    import torch.nn.functional as F
+    from src import _native as N
+    lib = N.lib()
+    torch.manual_seed(rows + V)
+    ld = (V + 63) // 64 * 64
+    x = (torch.randn(rows, ld, device=dev) * 2).to(dtype)
+    x[:, V:] = 0
+    ref_in = x[:count, :V].float().clone().requires_grad_(True)
+    tg = torch.randint(0, V, (rows,), device=dev, dtype=torch.int64)
+    cnt = torch.tensor([count], dtype=torch.int32, device=dev)
+    lse = torch.empty(rows, device=dev)
+    tmp = torch.empty(rows, device=dev)
+    out = torch.full((2,), -1.0, device=dev)
+    sentinel = x[(count + 63) // 64 * 64:].clone()
+    N.check(lib.ldm_ce_fwd_grad(x.data_ptr(), N.dtype_code(dtype), ld, rows, V, tg.data_ptr(), cnt.data_ptr(), 0, 0.0,
+                                lse.data_ptr(), tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), N.stream()),
+            "ldm_ce_fwd_grad")
+    assert float(out[1]) == count
+    if count == 0:
+        assert float(out[0]) == 0.0
+    else:
+        loss = F.cross_entropy(ref_in, tg[:count])
+        loss.backward()
+        assert abs(float(out[0]) - float(loss)) <= 1e-5 * abs(float(loss))
+        tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+        assert rel_err(x[:count, :V].float(), ref_in.grad) < tol
+        assert torch.allclose(lse[:count], torch.logsumexp(ref_in.detach(), -1), rtol=1e-5, atol=1e-5)
+    pad_rows = (count + 63) // 64 * 64
+    assert not x[:count, V:].any() and not x[count:pad_rows].any()
+    assert torch.equal(x[pad_rows:], sentinel)          # rows past the rounding are not touched
+    # upstream gradient != 1: scaled in place; == 1: untouched
+    if count:
+        before = x.clone()
+        one = torch.ones(1, device=dev)
+        N.check(lib.ldm_scale_rows_dev(x.data_ptr(), N.dtype_code(dtype), ld, rows, ld, cnt.data_ptr(), one.data_ptr(),
+                                       N.stream()), "ldm_scale_rows_dev")
+        assert torch.equal(x, before)
+        half = torch.full((1,), 0.5, device=dev)
+        N.check(lib.ldm_scale_rows_dev(x.data_ptr(), N.dtype_code(dtype), ld, rows, ld, cnt.data_ptr(), half.data_ptr(),
+                                       N.stream()), "ldm_scale_rows_dev")
+        assert torch.equal(x[:count], (before[:count].float() * 0.5).to(dtype)) and torch.equal(x[count:], before[count:])
