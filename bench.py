@@ -153,13 +153,16 @@ def main():
         torch.cuda.synchronize()
 
     last = 0.0
+    # loss_value(): the host reads every step's loss before it starts the next one, as the
+    # reference's `loss.item()` does; the copy is queued right behind the loss kernels
+    read = (lambda l: l.item()) if os.environ.get("LDM_ITEM_SYNC") else trainer.loss_value   # A/B switch
     for _ in range(args.warmup):
-        last = trainer._step(batch).item()
+        last = read(trainer._step(batch))
     sync()
     ops.GEMM_EVENTS = {"head.fwd": []}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last = trainer._step(batch).item()
+        last = read(trainer._step(batch))
     sync()
     elapsed = time.perf_counter() - t0
     events = ops.GEMM_EVENTS["head.fwd"]

@@ -24,6 +24,9 @@ class DiffusionLanguageModelTrainer:
         self.history: list[float] = []
         self.global_step = 0
         self.fused_head_loss = True   # False: model() then variational_lower_bound_loss(), as the reference spells it
+        self._loss_host = None        # pinned float the step's loss is copied to as soon as it exists
+        self._loss_event = None
+        self._staged = None
 
     def _step(self, batch) -> torch.Tensor:
         input_ids = batch["input_ids"]
@@ -38,17 +41,41 @@ class DiffusionLanguageModelTrainer:
             loss = variational_lower_bound_loss(logits=logits, targets=input_ids,
                                                 masked_input_ids=masked_input_ids, attention_mask=attention_mask,
                                                 mask_token_id=self.model.tokenizer.mask_token_id)
+        self._stage_loss(loss)
         self.accelerator.backward(loss)
         self.optimizer.step()
         self.global_step += 1
         return loss
+
+    def _stage_loss(self, loss: torch.Tensor) -> None:
+        """Queue the device-to-host copy of the loss value right behind the kernels that produce it,
+        i.e. BEFORE backward and the optimizer step are enqueued."""
+        if not loss.is_cuda:
+            self._staged = None
+            return
+        if self._loss_host is None:
+            self._loss_host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            self._loss_event = torch.cuda.Event()
+        self._loss_host.copy_(loss.detach().reshape(1), non_blocking=True)
+        self._loss_event.record()
+        self._staged = loss
+
+    def loss_value(self, loss: torch.Tensor) -> float:
+        """``loss.item()`` for the loss ``_step`` just returned (src/trainer.py:78,139 of the reference).
+        The value was copied to pinned host memory when it was produced, so the host waits for that
+        copy only, not for the backward pass and the optimizer step queued behind it: the GPU still
+        has work while the host prepares the next step."""
+        if self._staged is loss and loss.is_cuda:
+            self._loss_event.synchronize()
+            return float(self._loss_host[0])
+        return loss.item()
 
     def train_epoch(self, dataloader) -> float:
         self.model.train()
         total_loss = 0.0
         for batch in dataloader:
             loss = self._step(batch)
-            value = loss.item()
+            value = self.loss_value(loss)
             total_loss += value
             print(f"Step {self.global_step} Loss: {value:.4f}")
         epoch_loss = total_loss / len(dataloader)
@@ -66,7 +93,7 @@ class DiffusionLanguageModelTrainer:
             total_loss = 0.0
             for batch_idx, batch in enumerate(train_dataloader):
                 loss = self._step(batch)
-                value = loss.item()
+                value = self.loss_value(loss)
                 total_loss += value
                 if batch_idx % 10 == 0:
                     print(f"Epoch {epoch + 1}/{num_epochs} | Batch {batch_idx}/{len(train_dataloader)} | "
