@@ -14,6 +14,7 @@ dropout 0.0, per-GPU batch --batch (default 128 sequences = 65,536 tokens; weak 
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import random
@@ -102,6 +103,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
+                    help="hip: src.optim.FusedAdamW (one HIP pass, weight copies refreshed in it); torch: torch.optim.AdamW(fused=True)")
     args = ap.parse_args()
 
     if os.environ.get("LDM_FAULT_TIMEOUT"):     # debugging aid: dump python stacks if the run stalls
@@ -140,7 +143,11 @@ def main():
     acc = HipAccelerator(mixed_precision="bf16" if args.dtype == "bf16" else "no", device=dev,
                          bucket_bytes=args.bucket_mb << 20)
     model = acc.prepare(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
+    if args.optimizer == "hip":
+        from src.optim import FusedAdamW
+        opt = acc.prepare(FusedAdamW(model.parameters(), lr=5e-4, weight_decay=0.1))
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
     trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
     model.train()
 
@@ -159,6 +166,10 @@ def main():
     for _ in range(args.warmup):
         last = read(trainer._step(batch))
     sync()
+    # everything alive now (modules, torch internals) moves to the collector's permanent generation:
+    # a full collection over it pauses the host for ~80 ms, long enough to drain the GPU queue
+    gc.collect()
+    gc.freeze()
     ops.GEMM_EVENTS = {"head.fwd": []}
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -251,6 +251,26 @@ int ldm_ce_fwd_grad(void *logits, int dtype, int64_t ld, int64_t rows_alloc, int
 int ldm_scale_rows_dev(void *x, int dtype, int64_t ld, int64_t rows_alloc, int64_t ncols,
                        const int32_t *count, const float *scale, void *stream);
 
+/* ---------------------------------------------------------------- optimizer step
+ * torch.optim.AdamW as the reference builds it (main.py:87-91: lr, weight_decay; betas (0.9, 0.999),
+ * eps 1e-8 by default) and steps it (src/trainer.py:75,137), for `count` tensors in one pass:
+ *   g' = g * grad_scale;  p *= 1 - lr * weight_decay;  m += (g' - m)(1 - beta1);
+ *   v = beta2 v + (1 - beta2) g'^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `step` counts from 1.  grad_scale folds the 1 / world_size of a summing gradient all-reduce into the
+ * update.  shadow (nullable): a second copy of the updated parameter written by the same pass --
+ * shadow_kind 1 = bf16 (the weight copy the bf16 GEMMs read), 2 = fp32.  `tensors` is a HOST array;
+ * every pointer inside is a 16-byte aligned device pointer (bf16 shadow: 8-byte). */
+typedef struct {
+  float *p;
+  const float *g;
+  float *m, *v;
+  void *shadow;
+  int64_t n;
+  int32_t shadow_kind;
+} ldm_adamw_tensor;
+int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, void *stream);
+
 /* ---------------------------------------------------------------- reverse process: token selection
  * ldm_sample_tokens replaces what DiffusionLanguageModel.generate / sample do with the logits
  * (src/model.py:93-105 and :167-177): for every row whose id is mask_id (all_rows != 0: for

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 7   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -23,6 +23,11 @@ _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uin
 
 class BStride(C.Structure):
     _fields_ = [("outer", C.c_int64), ("inner", C.c_int64)]
+
+
+class AdamWTensor(C.Structure):     # ldm_adamw_tensor
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("shadow", C.c_void_p), ("n", C.c_int64), ("shadow_kind", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in sync with include/ldm_hip.h
@@ -65,6 +70,7 @@ SIGNATURES = {
                                   _i64, _vp]),
     "ldm_ce_fwd_grad": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ldm_scale_rows_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "ldm_adamw_step": (_i32, [C.POINTER(AdamWTensor), _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "ldm_gather_rows": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
     "ldm_gemm_rows_dyn": (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                  _vp]),

@@ -76,6 +76,9 @@ class GradBucketDataParallel(nn.Module):
             self._add_bucket(cur)
         self._callback_queued = False
         self._next = 0
+        # True: leave the SUM over ranks in the buckets; the optimizer applies 1 / world_size inside its
+        # update (FusedAdamW.grad_scale), which saves one pass over every gradient
+        self.defer_scale = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         # identical starting point on every rank (DDP broadcasts rank 0's state too)
         # gloo cannot be trusted with device memory here (two ranks sharing one GPU stall inside
@@ -160,7 +163,8 @@ class GradBucketDataParallel(nn.Module):
             if b.host is not None:
                 b.flat.copy_(b.host)
                 b.host = None
-            b.flat.mul_(inv)
+            if not self.defer_scale:
+                b.flat.mul_(inv)
             b.work = None
             b.ready.clear()
 
@@ -190,8 +194,24 @@ class HipAccelerator:
         self.is_main_process = self.process_index == 0
 
     def prepare(self, *objs):
+        from .optim import FusedAdamW
         out = []
         for o in objs:
+            if isinstance(o, FusedAdamW):
+                # the optimizer keeps the packed weight copies of the last prepared model current and,
+                # under data parallelism, takes over the 1 / world_size scaling of the summed gradients
+                model = getattr(self, "_last_model", None)
+                if model is not None:
+                    inner = model.module if isinstance(model, GradBucketDataParallel) else model
+                    o.attach(inner)
+                    if isinstance(model, GradBucketDataParallel) and model._active:
+                        model.defer_scale = True
+                        o.grad_scale = 1.0 / model.world_size
+            elif isinstance(o, torch.optim.Optimizer) and not getattr(o, "_ldm_epoch_hook", False):
+                # fused torch optimizers update parameters without moving their version counters
+                from . import ops
+                o.register_step_post_hook(lambda *_a, **_k: ops.parameters_changed())
+                o._ldm_epoch_hook = True
             if isinstance(o, nn.Module):
                 o = o.to(self.device)
                 dtype = torch.bfloat16 if self.mixed_precision == "bf16" else torch.float32
@@ -200,6 +220,7 @@ class HipAccelerator:
                         m.set_compute_dtype(dtype)
                 if self.num_processes > 1 or (dist.is_initialized() and os.environ.get("LDM_DP_FORCE") == "1"):
                     o = GradBucketDataParallel(o, bucket_bytes=self.bucket_bytes)
+                self._last_model = o
             out.append(o)
         return out[0] if len(out) == 1 else tuple(out)
 

@@ -60,6 +60,18 @@ def _rows2d(x: Tensor) -> Tensor:
 # that projections sharing an input run as ONE GEMM.  Rebuilt when a parameter's
 # version counter moves (i.e. after every optimizer step).
 # ----------------------------------------------------------------------------
+# Bumped whenever parameters may have changed WITHOUT their version counters moving: fused torch
+# optimizers (torch.optim.AdamW(fused=True)) and raw kernels update parameters in place and leave
+# ``_version`` alone.  The accelerator / trainer call ``parameters_changed()`` after such a step.
+WEIGHTS_EPOCH = 0
+
+
+def parameters_changed() -> None:
+    """Mark every packed compute-dtype weight copy stale (rebuilt by the next forward)."""
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
 class PackedWeights:
     def __init__(self, weights, biases, dtype: torch.dtype, name: str = "linear"):
         self.name = name
@@ -76,7 +88,7 @@ class PackedWeights:
         self.b = None
 
     def get(self):
-        key = tuple((p._version, p.data_ptr()) for p in self.weights + self.biases)
+        key = (WEIGHTS_EPOCH,) + tuple((p._version, p.data_ptr()) for p in self.weights + self.biases)
         if key != self._key or self.w is None or self.w.device != self.weights[0].device:
             dev = self.weights[0].device
             if self.w is None or self.w.device != dev:

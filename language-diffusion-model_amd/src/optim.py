@@ -1,0 +1,114 @@
+"""AdamW on one HIP kernel per (up to 24) tensors.
+
+``FusedAdamW(params, lr, betas, eps, weight_decay)`` applies the update of
+``torch.optim.AdamW`` -- the optimizer the reference builds at main.py:87-91 and steps at
+src/trainer.py:75,137 -- through ``ldm_adamw_step``: parameters, gradients and both moments are
+read once and written once, ``grad_scale`` folds a gradient scaling (1 / world size after a summing
+all-reduce) into the same pass, and the compute-dtype copies of the projection weights
+(``ops.PackedWeights``) are refreshed by it, so the next forward does not re-cast them.
+
+State layout and names follow torch (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter), so
+``state_dict()`` round-trips with ``torch.optim.AdamW``.  Parameters must be contiguous fp32 tensors
+on a ROCm device; there is no CPU path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.grad_scale = 1.0        # multiplies every gradient inside the update
+        self._shadows: dict = {}     # id(param) -> (tensor slice, kind)
+        self._shadow_sig = None
+
+    # ------------------------------------------------------------------ weight shadows
+    def attach(self, module: torch.nn.Module) -> "FusedAdamW":
+        """Let the step keep the packed compute-dtype weight copies of ``module`` current."""
+        self._module = module
+        self._shadow_sig = None
+        return self
+
+    def _refresh_shadows(self) -> None:
+        module = getattr(self, "_module", None)
+        if module is None:
+            return
+        packs = [pk for m in module.modules() for pk in getattr(m, "_packs", {}).values()]
+        sig = tuple((id(pk), id(pk.w)) for pk in packs)
+        if sig == self._shadow_sig:
+            return
+        self._shadows = {}
+        for pk in packs:
+            w, b = pk.get()                       # builds the copies if they do not exist yet
+            kind = 1 if w.dtype == torch.bfloat16 else 2
+            off = 0
+            for wt, bs, n in zip(pk.weights, pk.biases, pk.n_each):
+                self._shadows.setdefault(id(wt), []).append((w[off:off + n], kind))
+                self._shadows.setdefault(id(bs), []).append((b[off:off + n], 2))
+                off += n
+        self._shadow_sig = tuple((id(pk), id(pk.w)) for pk in packs)
+
+    # ------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._refresh_shadows()
+        if getattr(self, "_module", None) is None:
+            from . import ops
+            ops.parameters_changed()     # nobody keeps the packed weight copies current: re-cast lazily
+        lib = N.lib()
+        for group in self.param_groups:
+            entries = []
+            step_no = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                N.require_device(p, p.grad)
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("FusedAdamW needs contiguous fp32 parameters")
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                k = int(st["step"].item())
+                sh = self._shadows.get(id(p), [])
+                if len(sh) > 1:        # a parameter packed more than once: the extra copies are re-cast lazily
+                    raise RuntimeError("a parameter belongs to more than one weight pack of one dtype")
+                entries.append((k, p, g, st["exp_avg"], st["exp_avg_sq"], sh[0] if sh else None))
+            # tensors of one launch share the step count (bias correction); group by it
+            by_step: dict = {}
+            for e in entries:
+                by_step.setdefault(e[0], []).append(e)
+            for step_no, es in by_step.items():
+                arr = (N.AdamWTensor * len(es))()
+                keep = []
+                for i, (_, p, g, m, v, sh) in enumerate(es):
+                    arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+                    arr[i].n = p.numel()
+                    if sh is not None:
+                        arr[i].shadow, arr[i].shadow_kind = sh[0].data_ptr(), sh[1]
+                    else:
+                        arr[i].shadow, arr[i].shadow_kind = None, 0
+                    keep.append(g)
+                b1, b2 = group["betas"]
+                N.check(lib.ldm_adamw_step(arr, len(es), step_no, float(group["lr"]), float(b1), float(b2),
+                                           float(group["eps"]), float(group["weight_decay"]), float(self.grad_scale),
+                                           N.stream()), "ldm_adamw_step")
+        return loss

@@ -10,6 +10,8 @@ examples (src/trainer.py:195-319).
 
 from __future__ import annotations
 
+import gc
+
 import torch
 
 from .loss import variational_lower_bound_loss
@@ -27,6 +29,16 @@ class DiffusionLanguageModelTrainer:
         self._loss_host = None        # pinned float the step's loss is copied to as soon as it exists
         self._loss_event = None
         self._staged = None
+        self._gc_frozen = False
+        # an optimizer that neither refreshes the packed compute-dtype weight copies itself
+        # (src.optim.FusedAdamW attached to the model) nor is known to move the parameters' version
+        # counters: mark the copies stale after every step
+        from .optim import FusedAdamW
+        if (isinstance(optimizer, torch.optim.Optimizer) and not getattr(optimizer, "_ldm_epoch_hook", False)
+                and not (isinstance(optimizer, FusedAdamW) and getattr(optimizer, "_module", None) is not None)):
+            from . import ops
+            optimizer.register_step_post_hook(lambda *_a, **_k: ops.parameters_changed())
+            optimizer._ldm_epoch_hook = True
 
     def _step(self, batch) -> torch.Tensor:
         input_ids = batch["input_ids"]
@@ -45,6 +57,13 @@ class DiffusionLanguageModelTrainer:
         self.accelerator.backward(loss)
         self.optimizer.step()
         self.global_step += 1
+        if not self._gc_frozen:
+            # after the first step everything long-lived exists: park it in the collector's permanent
+            # generation, so that a later full collection does not pause the host (~80 ms with torch
+            # loaded) while the GPU queue runs dry
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
         return loss
 
     def _stage_loss(self, loss: torch.Tensor) -> None:

@@ -16,7 +16,11 @@ tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=10
 model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
 acc = HipAccelerator(mixed_precision="bf16", device=dev)
 model = acc.prepare(model)
-opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
+if os.environ.get("OPT", "hip") == "hip":
+    from src.optim import FusedAdamW
+    opt = acc.prepare(FusedAdamW(model.parameters(), lr=5e-4, weight_decay=0.1))
+else:
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
 trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
 model.train()
 B = int(os.environ.get("B", 128))
@@ -34,3 +38,23 @@ for _ in range(8):
     t2 = time.perf_counter()
     enq.append(t1 - t0); tot.append(t2 - t0)
 print(f"B={B}: host enqueue {1e3 * sum(enq) / len(enq):.2f} ms/step, step {1e3 * sum(tot) / len(tot):.2f} ms")
+
+# optimizer step alone: host time of the call, and GPU time between events
+torch.cuda.synchronize()
+hs = []
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); e0.record(); opt.step(); e1.record(); t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    hs.append((1e3 * (t1 - t0), e0.elapsed_time(e1)))
+print("optimizer.step(): host ms, gpu ms:", [(round(a, 2), round(b, 2)) for a, b in hs])
+if os.environ.get("CPROFILE"):
+    import cProfile, pstats
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        trainer.loss_value(trainer._step(batch))
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)

@@ -486,3 +486,44 @@ def test_ce_fwd_grad_one_pass(dev, dtype, rows, V, count):
         N.check(lib.ldm_scale_rows_dev(x.data_ptr(), N.dtype_code(dtype), ld, rows, ld, cnt.data_ptr(), half.data_ptr(),
                                        N.stream()), "ldm_scale_rows_dev")
         assert torch.equal(x[:count], (before[:count].float() * 0.5).to(dtype)) and torch.equal(x[count:], before[count:])
+
+
+def test_fused_adamw_matches_oracle_and_torch(dev):
+    """FusedAdamW (ldm_adamw_step) against the numpy restatement of torch.optim.AdamW and against
+    torch.optim.AdamW on the device: odd sizes (scalar tail), >24 tensors (two launches), a bf16 and an
+    fp32 shadow copy, and the gradient scale."""
+    from oracle.adamw_oracle import adamw_step
+    from src.optim import FusedAdamW
+    torch.manual_seed(5)
+    shapes = [(768, 768), (30522, 8), (5,), (1,), (4099,), (64, 1024)] + [(17 + i,) for i in range(24)]
+    ps = [torch.randn(*s, device=dev).requires_grad_(True) for s in shapes]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    opt = FusedAdamW(ps, lr=5e-4, weight_decay=0.1)
+    ref = torch.optim.AdamW(qs, lr=5e-4, weight_decay=0.1)
+    sh_bf = torch.zeros(768, 768, dtype=torch.bfloat16, device=dev)
+    sh_f = torch.zeros(4099, device=dev)
+    opt._shadows = {id(ps[0]): [(sh_bf, 1)], id(ps[4]): [(sh_f, 2)]}
+    orc = [(p.detach().cpu().numpy().copy(), np.zeros(s, np.float32), np.zeros(s, np.float32)) for p, s in zip(ps, shapes)]
+    for step in range(1, 6):
+        gs = [torch.randn(*s, device=dev) * step for s in shapes]
+        for p, q, g in zip(ps, qs, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        opt.step()
+        ref.step()
+        orc = [adamw_step(p, g.cpu().numpy(), m, v, step, lr=5e-4, weight_decay=0.1) for (p, m, v), g in zip(orc, gs)]
+        for p, q, (o, _, _) in zip(ps, qs, orc):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), step
+            assert np.allclose(p.detach().cpu().numpy(), o, rtol=1e-5, atol=1e-7), step
+        assert torch.equal(sh_bf, ps[0].detach().to(torch.bfloat16)) and torch.equal(sh_f, ps[4].detach())
+    # gradient scale: the same update as scaling the gradient first
+    a = torch.randn(1000, device=dev).requires_grad_(True)
+    b = a.detach().clone().requires_grad_(True)
+    oa, ob = FusedAdamW([a], lr=1e-3), FusedAdamW([b], lr=1e-3)
+    oa.grad_scale = 0.125
+    g = torch.randn(1000, device=dev)
+    a.grad, b.grad = g.clone(), g * 0.125
+    oa.step(); ob.step()
+    assert torch.equal(a, b)
+    # state_dict round trip with torch.optim.AdamW's layout
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}

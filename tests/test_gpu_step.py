@@ -302,3 +302,74 @@ def test_full_size_model_properties(dev):
     loss0.backward()
     assert loss0.item() == 0.0
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in tr.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_with_fused_adamw_tracks_torch_adamw(dev, dtype):
+    """Four trainer steps with src.optim.FusedAdamW (weight copies refreshed inside the update) and
+    with torch.optim.AdamW (copies re-cast by the next forward) from the same start, same masks."""
+    import random
+
+    from src.dp import HipAccelerator
+    from src.optim import FusedAdamW
+    from src.trainer import DiffusionLanguageModelTrainer
+    g = load_golden("step_hd96.npz")
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    att = torch.from_numpy(g["attention_mask"]).to(dev)
+    finals = []
+    for which in ("hip", "torch"):
+        model = _build(g, dev, dtype)
+        acc = HipAccelerator(mixed_precision="bf16" if dtype == torch.bfloat16 else "no", device=dev)
+        model = acc.prepare(model)
+        if which == "hip":
+            opt = acc.prepare(FusedAdamW(model.parameters(), lr=5e-4, weight_decay=0.1))
+        else:
+            opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1)
+        trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+        random.seed(1)
+        torch.manual_seed(1)
+        losses = [trainer.loss_value(trainer._step({"input_ids": ids, "attention_mask": att})) for _ in range(4)]
+        finals.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}, model))
+    (l_hip, p_hip, m_hip), (l_t, p_t, _) = finals
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert all(abs(a - b) <= tol * abs(b) for a, b in zip(l_hip, l_t)), (l_hip, l_t)
+    for n in p_hip:
+        assert rel_err(p_hip[n], p_t[n]) < (1e-5 if dtype == torch.float32 else 5e-3), n
+    # the packed weight copies the next forward will read equal the updated parameters
+    packs = [pk for m in m_hip.modules() for pk in getattr(m, "_packs", {}).values()]
+    assert packs
+    for pk in packs:
+        off = 0
+        for wt, bs, n in zip(pk.weights, pk.biases, pk.n_each):
+            assert torch.equal(pk.w[off:off + n], wt.detach().to(pk.w.dtype))
+            assert torch.equal(pk.b[off:off + n], bs.detach())
+            off += n
+
+
+def test_weight_copies_follow_a_fused_torch_optimizer(dev):
+    """torch.optim.AdamW(fused=True) updates parameters without moving their version counters; the
+    trainer marks the packed bf16 weight copies stale, so the next forward reads the new weights."""
+    import random
+
+    from src.dp import HipAccelerator
+    from src.trainer import DiffusionLanguageModelTrainer
+    g = load_golden("step_hd96.npz")
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    att = torch.from_numpy(g["attention_mask"]).to(dev)
+    model = _build(g, dev, torch.bfloat16)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1, fused=True)
+    trainer = DiffusionLanguageModelTrainer(model, opt, None, HipAccelerator(mixed_precision="bf16", device=dev))
+    random.seed(1)
+    torch.manual_seed(1)
+    for _ in range(2):
+        trainer._step({"input_ids": ids, "attention_mask": att})
+    model.eval()
+    with torch.no_grad():
+        model(input_ids=ids, attention_mask=att, t=torch.tensor([0.5], device=dev))   # a forward rebuilds stale copies
+    packs = [pk for m in model.modules() for pk in getattr(m, "_packs", {}).values()]
+    assert packs
+    for pk in packs:
+        off = 0
+        for wt, n in zip(pk.weights, pk.n_each):
+            assert torch.equal(pk.w[off:off + n], wt.detach().to(pk.w.dtype))
+            off += n

@@ -94,3 +94,23 @@ def test_gumbel_choice_follows_softmax():
     p = torch.softmax(logits.double() / 0.7, 0)
     chi2 = float(((freq - rows * p) ** 2 / (rows * p)).sum())
     assert chi2 < 30.0, chi2   # 6 degrees of freedom: P(chi2 > 30) ~ 4e-5
+
+
+def test_adamw_oracle_matches_torch_adamw():
+    """oracle/adamw_oracle.py against torch.optim.AdamW (the optimizer of main.py:87-91) on CPU."""
+    import numpy as np
+    import torch
+    from oracle.adamw_oracle import adamw_step
+    torch.manual_seed(3)
+    shapes = [(7, 5), (33,), (1,), (4, 3, 2)]
+    ps = [torch.randn(*s).requires_grad_(True) for s in shapes]
+    opt = torch.optim.AdamW(ps, lr=5e-4, weight_decay=0.1)
+    mine = [(p.detach().numpy().copy(), np.zeros(s, np.float32), np.zeros(s, np.float32)) for p, s in zip(ps, shapes)]
+    for step in range(1, 8):
+        gs = [torch.randn(*s) * (0.1 + step) for s in shapes]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        opt.step()
+        mine = [adamw_step(p, g.numpy(), m, v, step, lr=5e-4, weight_decay=0.1) for (p, m, v), g in zip(mine, gs)]
+        for p, (q, _, _) in zip(ps, mine):
+            assert np.allclose(p.detach().numpy(), q, rtol=2e-6, atol=1e-8), step
