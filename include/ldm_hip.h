@@ -271,6 +271,24 @@ typedef struct {
 int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, void *stream);
 
+/* ---------------------------------------------------------------- batch producer
+ * The batch contract of the training step, {"input_ids", "attention_mask"}: int64 [batch, smax] each
+ * (src/dataset.py:48, 126-127; src/trainer.py:120-121).
+ * ldm_collate_pad: collate_batch (src/dataset.py:26-48: pad_sequence of the ids and of the masks, padding
+ *   value 0) from the UNPADDED tokens: flat = the sequences of the batch back to back, offsets[batch+1]
+ *   their starts (both device pointers); ids_out[b, s] = flat[offsets[b] + s] or pad_id, mask_out = 1 / 0.
+ *   Only the real tokens cross the host link; smax >= the longest sequence.
+ * ldm_synth_tokens: synthetic batches made on the device.  Flat position i = b * seq + s uses word i & 3
+ *   of Philox4x32-10 block (counter = (i >> 2, offset), key = seed): id = id_lo + (word * (id_hi - id_lo)) >> 32;
+ *   column 0 = bos_id, column len-1 = eos_id, columns >= len = pad_id with mask 0, where
+ *   len = seq when min_len >= seq, else min_len + (word0(counter = (b, offset ^ 2^31)) * (seq - min_len + 1)) >> 32
+ *   (min_len is raised to 2).  No counterpart in the reference (its data comes from a text file). */
+int ldm_collate_pad(const int64_t *flat, const int64_t *offsets, int64_t batch, int64_t smax,
+                    int64_t pad_id, int64_t *ids_out, int64_t *mask_out, void *stream);
+int ldm_synth_tokens(int64_t batch, int64_t seq, int64_t id_lo, int64_t id_hi, int64_t bos_id,
+                     int64_t eos_id, int64_t pad_id, int64_t min_len, uint64_t seed, uint64_t offset,
+                     int64_t *ids_out, int64_t *mask_out, void *stream);
+
 /* ---------------------------------------------------------------- reverse process: token selection
  * ldm_sample_tokens replaces what DiffusionLanguageModel.generate / sample do with the logits
  * (src/model.py:93-105 and :167-177): for every row whose id is mask_id (all_rows != 0: for

@@ -95,7 +95,7 @@ extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int tra
                           sc, nullptr, nullptr, 0, batch, batch_inner, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 7; }
+extern "C" int ldm_abi_version(void) { return 8; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

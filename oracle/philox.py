@@ -57,3 +57,29 @@ def seq_t(batch, seed, offset, eps):
     # the kernel evaluates fmaf(u, 1-eps, eps) in fp32 with a single rounding
     one_m = np.float64(np.float32(1.0) - np.float32(eps))
     return np.float32(u * one_m + np.float64(np.float32(eps)))
+
+
+def synth_tokens(batch, seq, id_lo, id_hi, bos, eos, pad, min_len, seed, offset):
+    """The synthetic batch of ldm_synth_tokens: (ids int64 [batch, seq], mask int64 [batch, seq])."""
+    n = batch * seq
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    o0 = np.uint32(offset & 0x7FFFFFFF)
+    o1 = np.uint32((offset >> 31) & 0xFFFFFFFF)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    w = philox4x32_10((g & np.uint64(0xFFFFFFFF)).astype(np.uint32), (g >> np.uint64(32)).astype(np.uint32),
+                      np.full(g.shape, o0), np.full(g.shape, o1), k0, k1)
+    words = np.stack(w, axis=1).reshape(-1)[:n].astype(np.uint64)
+    ids = (np.int64(id_lo) + ((words * np.uint64(id_hi - id_lo)) >> np.uint64(32)).astype(np.int64)).reshape(batch, seq)
+    min_len = min(max(min_len, 2 if seq >= 2 else min_len), seq)
+    if min_len >= seq:
+        lens = np.full(batch, seq, dtype=np.int64)
+    else:
+        b = np.arange(batch, dtype=np.uint64)
+        wl = philox4x32_10((b & np.uint64(0xFFFFFFFF)).astype(np.uint32), (b >> np.uint64(32)).astype(np.uint32),
+                           np.full(b.shape, np.uint32(o0 ^ np.uint32(0x80000000))), np.full(b.shape, o1), k0, k1)[0]
+        lens = min_len + ((wl.astype(np.uint64) * np.uint64(seq - min_len + 1)) >> np.uint64(32)).astype(np.int64)
+    col = np.arange(seq, dtype=np.int64)[None, :]
+    ids[:, 0] = bos
+    ids[np.arange(batch), lens - 1] = np.where(lens - 1 == 0, ids[np.arange(batch), lens - 1], eos)
+    ids = np.where(col >= lens[:, None], np.int64(pad), ids)
+    return ids, (col < lens[:, None]).astype(np.int64)

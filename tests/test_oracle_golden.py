@@ -114,3 +114,19 @@ def test_adamw_oracle_matches_torch_adamw():
         mine = [adamw_step(p, g.numpy(), m, v, step, lr=5e-4, weight_decay=0.1) for (p, m, v), g in zip(mine, gs)]
         for p, (q, _, _) in zip(ps, mine):
             assert np.allclose(p.detach().numpy(), q, rtol=2e-6, atol=1e-8), step
+
+
+def test_synth_token_oracle_contract():
+    """oracle/philox.py synth_tokens: the batch contract (src/dataset.py:48) and determinism."""
+    import numpy as np
+    from oracle.philox import synth_tokens
+    ids, mask = synth_tokens(6, 50, 1000, 30522, 101, 102, 0, 7, seed=11, offset=3)
+    ids2, mask2 = synth_tokens(6, 50, 1000, 30522, 101, 102, 0, 7, seed=11, offset=3)
+    assert np.array_equal(ids, ids2) and np.array_equal(mask, mask2)
+    assert ids.dtype == np.int64 and mask.dtype == np.int64 and ids.shape == (6, 50)
+    lens = mask.sum(1)
+    assert (lens >= 7).all() and (lens <= 50).all() and len(set(lens.tolist())) > 1
+    assert (ids[:, 0] == 101).all() and (ids[np.arange(6), lens - 1] == 102).all()
+    assert (ids[mask == 0] == 0).all()
+    full, fmask = synth_tokens(2, 9, 1000, 30522, 101, 102, 0, 9, seed=11, offset=0)
+    assert fmask.all() and (full[:, -1] == 102).all()
