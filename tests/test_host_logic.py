@@ -65,3 +65,49 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError, match="ROCm device"):
         masked_cross_entropy_loss(torch.zeros(1, 2, 4), torch.zeros(1, 2, dtype=torch.long),
                                   torch.ones(1, 2, dtype=torch.bool))
+
+
+def test_weight_copy_epoch_and_loss_value_host_logic():
+    """Host logic that needs no GPU: packed weight copies are rebuilt after parameters_changed()
+    (optimizers that do not move version counters), and trainer.loss_value falls back to item()."""
+    import torch
+    from src import ops
+    from src.trainer import DiffusionLanguageModelTrainer
+    lin = torch.nn.Linear(8, 4)
+    pack = ops.PackedWeights([lin.weight], [lin.bias], torch.float32)
+    w0, _ = pack.get()
+    assert torch.equal(w0[:4], lin.weight.detach())
+    with torch.no_grad():
+        lin.weight.data_ptr()                      # raw in-place change that leaves _version alone
+        torch._foreach_mul_([lin.weight.data], 2.0)
+    stale, _ = pack.get()
+    v_before = lin.weight._version
+    ops.parameters_changed()
+    fresh, _ = pack.get()
+    assert lin.weight._version == v_before
+    assert torch.equal(fresh[:4], lin.weight.detach())
+    assert stale is fresh                          # same buffer, refreshed in place
+
+    class _Opt(torch.optim.SGD):
+        pass
+    opt = _Opt(lin.parameters(), lr=0.1)
+    tr = DiffusionLanguageModelTrainer(lin, opt, None, None)
+    assert getattr(opt, "_ldm_epoch_hook", False)  # the trainer marks copies stale after every step
+    e0 = ops.WEIGHTS_EPOCH
+    lin(torch.randn(2, 8)).sum().backward()
+    opt.step()
+    assert ops.WEIGHTS_EPOCH == e0 + 1
+    assert tr.loss_value(torch.tensor(1.5)) == 1.5
+
+
+def test_fused_adamw_refuses_host_tensors():
+    import pytest
+    import torch
+    from src.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.randn(4))
+    p.grad = torch.randn(4)
+    opt = FusedAdamW([p], lr=1e-3)
+    with pytest.raises(RuntimeError):
+        opt.step()
+    with pytest.raises(ValueError):
+        FusedAdamW([p], lr=-1.0)
