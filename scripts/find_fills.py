@@ -17,7 +17,8 @@ tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=10
 model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
 acc = HipAccelerator(mixed_precision="bf16", device=dev)
 model = acc.prepare(model)
-opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
+from src.optim import FusedAdamW
+opt = acc.prepare(FusedAdamW(model.parameters(), lr=5e-4, weight_decay=0.1))
 trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
 model.train()
 ids, att = bench.synthetic_tokens(16, 512, cfg["vocab_size"], 1234)
@@ -27,8 +28,8 @@ for _ in range(2):
 with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
     trainer._step(batch).item()
 rows = []
-for ev in prof.key_averages(group_by_stack_n=8):
-    if ev.key in ("aten::fill_", "aten::zero_"):
+for ev in prof.key_averages(group_by_stack_n=12):
+    if ev.key in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::ones", "aten::full", "aten::zeros_like"):
         st = [f for f in (ev.stack or []) if "dist-packages/torch" not in f and "built-in" not in f]
         rows.append((ev.count, ev.key, (st[0] if st else (ev.stack[0] if ev.stack else "?"))[-120:]))
 for r in sorted(rows, reverse=True)[:25]:
