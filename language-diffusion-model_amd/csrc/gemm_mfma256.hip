@@ -157,7 +157,7 @@ __device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int
 // PERSISTENT: gridDim.x workgroups (one per CU) walk the work items w = blockIdx.x,
 // blockIdx.x + gridDim.x, ...; the LDS-DMA of the NEXT item's first three half-tiles is issued
 // before the epilogue of the current one, so the store tail and the load latency overlap.
-template <bool A_KC, bool B_KC, int BN, typename TO, int EPI>
+template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, bool RES = false>
 __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   constexpr int WN_ = BN / 64;            // waves along N
   constexpr int WM_ = 8 / WN_;            // waves along M
@@ -333,6 +333,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // All reads of the ring are complete for every wave (lgkmcnt(0) before each barrier) and
     // no LDS-DMA is outstanding: slots 0-2 can take the next item's first half-tiles now.
 
+    // Fast-path epilogue with a residual (bf16 output): the residual rows of this wave's tile are
+    // loaded 16 bytes per lane exactly where the stores will go, in batches of RQ loads held in two
+    // register banks: batch 0 is issued HERE, before the next item's LDS-DMA prefetch (so its
+    // latency runs under the prefetch set-up), batch k+2 as soon as batch k has been consumed.
+    constexpr bool RES_FAST = RES && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
+    typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+    const bool fast_tile = EPI == 0 && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0;
+    const bool res_fast = RES_FAST && fast_tile && g.R != nullptr && (g.ldr % CPL) == 0;
+    // RQ loads (a quarter of the tile's 2 MI store positions) per batch, two batches in registers
+    constexpr int RQ = MI / 2;
+    u4v_t rr[RES_FAST ? 2 * RQ : 1];
+    const TO *rrow = nullptr;
+    if (RES_FAST && res_fast) {
+      rrow = (const TO *)g.R + (m0 + wm * (MI * 16) + lane / LPR) * g.ldr + nw + (lane % LPR) * CPL;
+#pragma unroll
+      for (int i = 0; i < RQ; ++i)
+        rr[i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr);
+    }
+
     w += gridDim.x;
     const bool more = w < total;
     if (more) {
@@ -362,8 +381,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // compiler does not order them behind the LDS-DMA prefetch just issued (it would drain it
     // with vmcnt(0): it cannot see that the staging area and the ring are disjoint), and with a
     // fixed number of unconditional 16-byte stores (NST), which the next item's waits count on.
-    if (EPI == 0 && !g.R && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0) {
+    if (EPI == 0 && fast_tile && (!g.R || res_fast)) {
       TO *C = (TO *)g.C;
+      if (RES_FAST && res_fast) {
+        // batch 1 goes out before batch 0 is used (the compiler places the waits: loads return in order)
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) rr[RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(RQ + i) * RPP * g.ldr);
+      }
       const int cl = lane % LPR;
       const int wrow = lane & 15;
       const unsigned waddr = stage_lds + wrow * 256;
@@ -388,14 +412,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           }
           if (CPL == 8) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[CPL / 4 - 1])::"memory");
+            float o8[8] = {t[0][0] + bv[0], t[0][1] + bv[1], t[0][2] + bv[2], t[0][3] + bv[3],
+                           t[CPL / 4 - 1][0] + bv[CPL - 4], t[CPL / 4 - 1][1] + bv[CPL - 3],
+                           t[CPL / 4 - 1][2] + bv[CPL - 2], t[CPL / 4 - 1][3] + bv[CPL - 1]};
+            if (RES_FAST && res_fast) {
+              constexpr int IPM = 16 / RPP;                 // store instructions per 16-row fragment
+              const int ri = mi * IPM + it;                 // index of this store = index of its residual load
+              const int bank = (ri / RQ) & 1;
+              const u4v_t rv = rr[bank * RQ + ri % RQ];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                o8[2 * j] += __uint_as_float(rv[j] << 16);
+                o8[2 * j + 1] += __uint_as_float(rv[j] & 0xffff0000u);
+              }
+              // the bank just emptied takes the batch after next (issued after this batch's last use)
+              if (ri % RQ == RQ - 1 && ri + 1 + RQ < 2 * MI) {
+#pragma unroll
+                for (int i = 0; i < RQ; ++i)
+                  rr[bank * RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(ri + 1 + RQ + i) * RPP * g.ldr);
+              }
+            }
             // non-temporal: the tile is not read again by this kernel, and keeping it out of the
             // way of the operand panels in L2 is worth +17 % on the LM-head GEMM (2 GB of logits)
-            typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
             u4v_t pk;
-            pk[0] = pack_bf16x2(t[0][0] + bv[0], t[0][1] + bv[1]);
-            pk[1] = pack_bf16x2(t[0][2] + bv[2], t[0][3] + bv[3]);
-            pk[2] = pack_bf16x2(t[CPL / 4 - 1][0] + bv[CPL - 4], t[CPL / 4 - 1][1] + bv[CPL - 3]);
-            pk[3] = pack_bf16x2(t[CPL / 4 - 1][2] + bv[CPL - 2], t[CPL / 4 - 1][3] + bv[CPL - 1]);
+            pk[0] = pack_bf16x2(o8[0], o8[1]);
+            pk[1] = pack_bf16x2(o8[2], o8[3]);
+            pk[2] = pack_bf16x2(o8[4], o8[5]);
+            pk[3] = pack_bf16x2(o8[6], o8[7]);
             __builtin_nontemporal_store(pk, reinterpret_cast<u4v_t *>(crow));
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0])::"memory");
@@ -509,17 +552,17 @@ int num_cus() {
   return n;
 }
 
-template <bool A_KC, bool B_KC, int BN, typename TO, int EPI>
+template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, bool RES = false>
 int launch256(const MArgs &g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)gemm256_k<A_KC, B_KC, BN, TO, EPI>,
+    (void)hipFuncSetAttribute((const void *)gemm256_k<A_KC, B_KC, BN, TO, EPI, RES>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   const int64_t items = (int64_t)g.tiles_m * g.tiles_n * g.splits;
   const int64_t nwg = items < num_cus() ? items : num_cus();   // persistent: one workgroup per CU
-  hipLaunchKernelGGL((gemm256_k<A_KC, B_KC, BN, TO, EPI>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, s, g);
+  hipLaunchKernelGGL((gemm256_k<A_KC, B_KC, BN, TO, EPI, RES>), dim3((unsigned)nwg), dim3(512), LDS_BYTES, s, g);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }
@@ -575,8 +618,12 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
   g.tiles_m = (int)tm;
   g.tiles_n = (int)ceil_div(N, use128 ? 128 : 256);
   const bool akc = !transA, bkc = transB != 0;
-  if (out_dtype == LDM_BF16)
+  if (out_dtype == LDM_BF16) {
+    // projection + bias + residual (out-projection, MLP down-projection): the kernel variant whose
+    // epilogue streams the residual rows in around the next tile's prefetch
+    if (!use128 && R && akc && bkc && ldr % 8 == 0 && ldc % 8 == 0) return launch256<true, true, 256, bf16_t, 0, true>(g, s);
     return use128 ? dispatch_layout<128, bf16_t, 0>(g, akc, bkc, s) : dispatch_layout<256, bf16_t, 0>(g, akc, bkc, s);
+  }
   if (out_dtype == LDM_F32)
     return use128 ? dispatch_layout<128, float, 0>(g, akc, bkc, s) : dispatch_layout<256, float, 0>(g, akc, bkc, s);
   return LDM_E_DTYPE;
