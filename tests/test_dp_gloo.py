@@ -52,6 +52,14 @@ def _worker(rank, world, port, q):
         x = torch.randn(5 + rank, 16, generator=g)
         dp(x, use_extra).pow(2).mean().backward()
         out[step] = {n: p.grad.clone().numpy() for n, p in net.named_parameters()}
+    # deferred scaling: the buckets keep the SUM over ranks (an optimizer applies 1 / world_size)
+    dp.defer_scale = True
+    for p in net.parameters():
+        p.grad = None
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(5 + rank, 16, generator=g)
+    dp(x, True).pow(2).mean().backward()
+    out[2] = {n: p.grad.clone().numpy() for n, p in net.named_parameters()}
     # numpy payloads: torch tensors would travel as shared-memory handles that die with this process
     q.put((rank, out, {n: p.detach().clone().numpy() for n, p in net.named_parameters()}))
     dist.barrier()
@@ -85,3 +93,7 @@ def test_bucketed_allreduce_two_ranks():
         for r in range(2):
             for n, g in res[r][0][step].items():
                 assert torch.allclose(torch.from_numpy(g), want[n], rtol=1e-6, atol=1e-7), (step, r, n)
+    # step 2 ran with defer_scale: gradients are the sum, i.e. twice the mean of step 1's inputs
+    for r in range(2):
+        for n, g in res[r][0][2].items():
+            assert torch.allclose(torch.from_numpy(g), 2 * want[n], rtol=1e-6, atol=1e-7), ("deferred", r, n)
