@@ -36,13 +36,16 @@ from torch.autograd import Variable
 class _Bucket:
     def __init__(self, params, device):
         self.params = params
-        self.numel = sum(p.numel() for p in params)
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        # every slice starts on a 256-byte boundary (kernels that take the gradient views, e.g. the
+        # AdamW pass, want 16-byte aligned pointers; a vocabulary bias of 30522 floats is not a
+        # multiple of that); the padding elements stay zero
         self.offsets = {}
         off = 0
         for p in params:
             self.offsets[p] = off
-            off += p.numel()
+            off += (p.numel() + 63) // 64 * 64
+        self.numel = off
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.pending = len(params)
         self.ready = set()
         self.work = None

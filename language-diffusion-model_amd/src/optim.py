@@ -81,6 +81,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 g = p.grad
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.float().contiguous()
+                if g.data_ptr() % 16:          # a view at an odd offset of a larger buffer
+                    g = g.clone()
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0)
