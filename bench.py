@@ -9,7 +9,8 @@ zero_grad -> forward masking -> transformer forward -> masked CE -> backward (wi
 RCCL gradient all-reduce when N > 1) -> AdamW.step -> loss.item(), on synthetic tokens that are
 resident in HBM before the timed region.  Workload: the reference's configs/default.yaml model
 (d=768, 8 heads of 96, 8 layers, ff=1024, vocab 30522) at sequence length 512, bf16 compute,
-dropout 0.0, per-GPU batch --batch (default 128 sequences = 65,536 tokens; weak scaling).  Rank 0 prints ONE JSON line.
+dropout 0.0, per-GPU batch --batch (default 512 sequences, the YAML's own batch_size, = 262,144 tokens per
+GPU per step; weak scaling).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -98,7 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="default", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step")
+    ap.add_argument("--batch", type=int, default=512,
+                    help="sequences per GPU per step (configs/default.yaml:23 batch_size = 512)")
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
