@@ -228,14 +228,14 @@ __global__ __launch_bounds__(1024) void ce_compact_k(CeArgs a, int *rows, int *c
   if (threadIdx.x == 0) count[0] = base;
 }
 
-// Multi-block compaction: block b owns rows [1024 b, 1024 b + 1024) and counts the participating
-// rows BEFORE its chunk itself (independent flag reads, eight in flight), so no block waits for
-// another; the last block also writes the total.  Same output as ce_compact_k.
-__global__ __launch_bounds__(1024) void ce_compact_mb_k(CeArgs a, int *rows, int *count) {
+// Multi-block compaction: block b owns `sub` consecutive 1024-row pieces and counts the
+// participating rows BEFORE its first row itself (independent flag reads, eight in flight), so no
+// block waits for another; the last block also writes the total.  Same output as ce_compact_k.
+__global__ __launch_bounds__(1024) void ce_compact_mb_k(CeArgs a, int *rows, int *count, int sub) {
   __shared__ int wsum[16];
   __shared__ int wpre[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t start = (int64_t)blockIdx.x * 1024;
+  const int64_t start = (int64_t)blockIdx.x * sub * 1024;
   int mine = 0;
   int64_t r = threadIdx.x;
   for (; r + 7 * 1024 < start; r += 8 * 1024) {
@@ -249,21 +249,29 @@ __global__ __launch_bounds__(1024) void ce_compact_mb_k(CeArgs a, int *rows, int
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
   if (lane == 0) wpre[wid] = mine;
-  const int64_t rr = start + threadIdx.x;
-  const bool act = rr < a.T && row_active(a, rr);
-  const unsigned long long m = __ballot(act);
-  if (lane == 0) wsum[wid] = __popcll(m);
   __syncthreads();
-  int base = 0, before = 0, total = 0;
+  int base = 0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    base += wpre[w];
-    const int c = wsum[w];
-    before += w < wid ? c : 0;
-    total += c;
+  for (int w = 0; w < 16; ++w) base += wpre[w];
+  for (int s = 0; s < sub; ++s) {
+    const int64_t rr = start + (int64_t)s * 1024 + threadIdx.x;
+    if (start + (int64_t)s * 1024 >= a.T) break;          // block-uniform
+    const bool act = rr < a.T && row_active(a, rr);
+    const unsigned long long m = __ballot(act);
+    if (lane == 0) wsum[wid] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int c = wsum[w];
+      before += w < wid ? c : 0;
+      total += c;
+    }
+    if (act) rows[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (int)rr;
+    base += total;
+    __syncthreads();
   }
-  if (act) rows[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (int)rr;
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count[0] = base + total;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count[0] = base;
 }
 
 // Backward into the COMPACT layout: block i handles compact row i (source row rows[i]);
@@ -687,9 +695,12 @@ extern "C" int ldm_ce_compact_rows(int64_t T, int64_t seq, const int64_t *masked
   CeArgs a{};
   a.T = T; a.V = 1; a.ld = 1; a.seq = seq > 0 ? seq : 1; a.masked_ids = masked_ids; a.mask_token_id = mask_token_id;
   a.mask_bool = mask_bool; a.att_valid = att_valid;
-  if (T > 1024 && T <= (1 << 18))
-    hipLaunchKernelGGL(ce_compact_mb_k, dim3((unsigned)((T + 1023) / 1024)), dim3(1024), 0, (hipStream_t)stream, a, rows, count);
-  else
+  if (T > 1024 && T <= (1 << 24)) {
+    // at most 64 blocks: the rows before a block are re-counted by it, which is quadratic in the block count
+    const int sub = (int)((T + 64 * 1024 - 1) / (64 * 1024));
+    const unsigned nb = (unsigned)((T + (int64_t)sub * 1024 - 1) / ((int64_t)sub * 1024));
+    hipLaunchKernelGGL(ce_compact_mb_k, dim3(nb), dim3(1024), 0, (hipStream_t)stream, a, rows, count, sub);
+  } else
     hipLaunchKernelGGL(ce_compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, rows, count);
   LDM_CHECK_LAUNCH();
   return LDM_OK;

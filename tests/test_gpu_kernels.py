@@ -375,7 +375,7 @@ def test_attention_bwd_fused_unrope_matches_two_pass(dev, B, S, H, hd):
     assert torch.equal(grads[True].view(B, S, 3, D)[:, :, 2], grads[False].view(B, S, 3, D)[:, :, 2])   # dv untouched
 
 
-@pytest.mark.parametrize("T", [1, 63, 1024, 1250, 65536 + 17])
+@pytest.mark.parametrize("T", [1, 63, 1024, 1250, 65536 + 17, 262144, 300001])
 def test_ce_compact_rows(dev, T):
     """rows[0..count) = ascending indices where masked id == mask token and attention == 1."""
     from src import _native as Nn
