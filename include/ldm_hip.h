@@ -137,6 +137,17 @@ int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_
                      const void *B, int64_t ldb, ldm_bstride sb, void *C, int64_t ldc,
                      ldm_bstride sc, int64_t batch, int64_t batch_inner, void *stream);
 
+/* The SwiGLU backward as the epilogue of the down-projection's input-gradient GEMM (BF16, MFMA):
+ * SwiGLU.forward (src/transformer.py:91-95) is w3(a * silu(g)) with ag = [a | g] = [w1(x) | w2(x)]; under
+ * autograd the gradient of the hidden activation is dh = dy * W3 (dy [T, K], W3 stored [K, F]) and
+ *   dag[:, :F] = dh * silu(g),   dag[:, F:] = dh * a * sigmoid(g) * (1 + g * (1 - sigmoid(g))).
+ * This entry point writes dag [T, 2F] without writing dh: exactly what ldm_gemm (dh) followed by
+ * ldm_swiglu_bwd leaves, up to the bf16 rounding of dh that the two-call form goes through.
+ * T and F must be multiples of 256, row strides multiples of 8; otherwise LDM_E_SHAPE / LDM_E_ALIGN
+ * (the caller then makes the two calls). */
+int ldm_gemm_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
+                        int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag, void *stream);
+
 /* Column sums (bias gradients): out[n] = sum_m X[m,n]; out fp32 [N], overwritten.
  * ws must hold ldm_colsum_ws_floats(M,N) floats. */
 int64_t ldm_colsum_ws_floats(int64_t M, int64_t N);

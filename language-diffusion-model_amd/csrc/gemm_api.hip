@@ -95,7 +95,14 @@ extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int tra
                           sc, nullptr, nullptr, 0, batch, batch_inner, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 8; }
+extern "C" int ldm_gemm_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
+                                   int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag,
+                                   void *stream) {
+  if (T <= 0 || F <= 0 || K <= 0 || !dy || !W || !ag || !dag) return LDM_E_BADARG;
+  return ldm_gemm_mfma256_bf16_swiglu_bwd(T, F, K, dy, ld_dy, W, ldw, ag, ld_ag, dag, ld_dag, (hipStream_t)stream);
+}
+
+extern "C" int ldm_abi_version(void) { return 9; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

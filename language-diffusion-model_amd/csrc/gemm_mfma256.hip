@@ -52,6 +52,7 @@ struct MArgs {
   void *C; int64_t ldc;
   const float *bias;
   const void *R; int64_t ldr;
+  int64_t gate_off;   // RES 2: columns of the gate half in R and C (R = [a | g], C = [da | dg])
   int tiles_m, tiles_n, splits;
   // optional device-side sizes (a row count known only on the GPU): rows >= *dyn_m of A/C do
   // not exist; K is *dyn_k rounded up to 32 (the caller zero-fills the rounding rows);
@@ -157,7 +158,7 @@ __device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int
 // PERSISTENT: gridDim.x workgroups (one per CU) walk the work items w = blockIdx.x,
 // blockIdx.x + gridDim.x, ...; the LDS-DMA of the NEXT item's first three half-tiles is issued
 // before the epilogue of the current one, so the store tail and the load latency overlap.
-template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, bool RES = false>
+template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, int RES = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   constexpr int WN_ = BN / 64;            // waves along N
   constexpr int WM_ = 8 / WN_;            // waves along M
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     }
 
   // stores per wave in the fast-path epilogue (16 bytes per lane each)
-  constexpr int NST = MI * (sizeof(TO) == 2 ? 2 : 4);
+  constexpr int NST = MI * (sizeof(TO) == 2 ? 2 : 4) * (RES == 2 ? 2 : 1);
   static_assert(2 * P + NST <= 63, "vmcnt is a 6-bit counter");
 #ifdef LDM_GEMM_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -337,14 +338,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // loaded 16 bytes per lane exactly where the stores will go, in batches of RQ loads held in two
     // register banks: batch 0 is issued HERE, before the next item's LDS-DMA prefetch (so its
     // latency runs under the prefetch set-up), batch k+2 as soon as batch k has been consumed.
-    constexpr bool RES_FAST = RES && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
+    constexpr bool RES_FAST = RES == 1 && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
+    // RES 2: C = [dh * silu(g) | dh * a * silu'(g)] with dh the product and [a | g] read from R (SwiGLU backward)
+    constexpr bool SWI_FAST = RES == 2 && EPI == 0 && sizeof(TO) == 2 && MI == 8;
     typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
     const bool fast_tile = EPI == 0 && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0;
     const bool res_fast = RES_FAST && fast_tile && g.R != nullptr && (g.ldr % CPL) == 0;
     // RQ loads (a quarter of the tile's 2 MI store positions) per batch, two batches in registers
     constexpr int RQ = MI / 2;
-    u4v_t rr[RES_FAST ? 2 * RQ : 1];
+    u4v_t rr[(RES_FAST || SWI_FAST) ? 2 * RQ : 1];   // SWI: per bank (a0, a1, g0, g1) of two store positions
     const TO *rrow = nullptr;
+    if (SWI_FAST) {
+      rrow = (const TO *)g.R + (m0 + wm * (MI * 16) + lane / LPR) * g.ldr + nw + (lane % LPR) * CPL;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rr[i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr);
+        rr[2 + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr + g.gate_off);
+      }
+    }
     if (RES_FAST && res_fast) {
       rrow = (const TO *)g.R + (m0 + wm * (MI * 16) + lane / LPR) * g.ldr + nw + (lane % LPR) * CPL;
 #pragma unroll
@@ -381,8 +392,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // compiler does not order them behind the LDS-DMA prefetch just issued (it would drain it
     // with vmcnt(0): it cannot see that the staging area and the ring are disjoint), and with a
     // fixed number of unconditional 16-byte stores (NST), which the next item's waits count on.
-    if (EPI == 0 && fast_tile && (!g.R || res_fast)) {
+    if (EPI == 0 && (SWI_FAST || (fast_tile && (!g.R || res_fast)))) {
       TO *C = (TO *)g.C;
+      if (SWI_FAST) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          rr[RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(2 + i) * RPP * g.ldr);
+          rr[RQ + 2 + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(2 + i) * RPP * g.ldr + g.gate_off);
+        }
+      }
       if (RES_FAST && res_fast) {
         // batch 1 goes out before batch 0 is used (the compiler places the waits: loads return in order)
 #pragma unroll
@@ -415,6 +433,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
             float o8[8] = {t[0][0] + bv[0], t[0][1] + bv[1], t[0][2] + bv[2], t[0][3] + bv[3],
                            t[CPL / 4 - 1][0] + bv[CPL - 4], t[CPL / 4 - 1][1] + bv[CPL - 3],
                            t[CPL / 4 - 1][2] + bv[CPL - 2], t[CPL / 4 - 1][3] + bv[CPL - 1]};
+            if (SWI_FAST) {
+              constexpr int IPM = 16 / RPP;
+              const int ri = mi * IPM + it;                 // store position; batches of two positions
+              const int bank = (ri >> 1) & 1;
+              const u4v_t av = rr[bank * RQ + (ri & 1)], gv = rr[bank * RQ + 2 + (ri & 1)];
+              float dg8[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const unsigned aw = av[j >> 1], gw = gv[j >> 1];
+                const float a_ = (j & 1) ? __uint_as_float(aw & 0xffff0000u) : __uint_as_float(aw << 16);
+                const float g_ = (j & 1) ? __uint_as_float(gw & 0xffff0000u) : __uint_as_float(gw << 16);
+                const float sg = 1.0f / (1.0f + __expf(-g_));
+                const float dh = o8[j];
+                o8[j] = dh * (g_ * sg);
+                dg8[j] = dh * a_ * sg * (1.0f + g_ * (1.0f - sg));
+              }
+              if ((ri & 1) && ri + 3 < 2 * MI) {             // this bank is free: the batch after next
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  rr[bank * RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(ri + 3 + i) * RPP * g.ldr);
+                  rr[bank * RQ + 2 + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(ri + 3 + i) * RPP * g.ldr + g.gate_off);
+                }
+              }
+              u4v_t pg;
+              pg[0] = pack_bf16x2(dg8[0], dg8[1]);
+              pg[1] = pack_bf16x2(dg8[2], dg8[3]);
+              pg[2] = pack_bf16x2(dg8[4], dg8[5]);
+              pg[3] = pack_bf16x2(dg8[6], dg8[7]);
+              __builtin_nontemporal_store(pg, reinterpret_cast<u4v_t *>(crow + g.gate_off));
+            }
             if (RES_FAST && res_fast) {
               constexpr int IPM = 16 / RPP;                 // store instructions per 16-row fragment
               const int ri = mi * IPM + it;                 // index of this store = index of its residual load
@@ -552,7 +600,7 @@ int num_cus() {
   return n;
 }
 
-template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, bool RES = false>
+template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, int RES = 0>
 int launch256(const MArgs &g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -588,6 +636,7 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.M = M; g.N = N; g.K = K; g.alpha = alpha;
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
+  g.gate_off = 0;
   g.splits = 1;
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
   g.rowsum = nullptr;
@@ -621,12 +670,33 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
   if (out_dtype == LDM_BF16) {
     // projection + bias + residual (out-projection, MLP down-projection): the kernel variant whose
     // epilogue streams the residual rows in around the next tile's prefetch
-    if (!use128 && R && akc && bkc && ldr % 8 == 0 && ldc % 8 == 0) return launch256<true, true, 256, bf16_t, 0, true>(g, s);
+    if (!use128 && R && akc && bkc && ldr % 8 == 0 && ldc % 8 == 0) return launch256<true, true, 256, bf16_t, 0, 1>(g, s);
     return use128 ? dispatch_layout<128, bf16_t, 0>(g, akc, bkc, s) : dispatch_layout<256, bf16_t, 0>(g, akc, bkc, s);
   }
   if (out_dtype == LDM_F32)
     return use128 ? dispatch_layout<128, float, 0>(g, akc, bkc, s) : dispatch_layout<256, float, 0>(g, akc, bkc, s);
   return LDM_E_DTYPE;
+}
+
+// dag[T, 2F] = [ dh * silu(g) | dh * a * silu'(g) ] with dh = dy[T, K] * W[K, F] never written to memory:
+// the SwiGLU backward (src/transformer.py:93 under autograd) as the epilogue of the down-projection's
+// input-gradient GEMM.  ag = [a | g] and dag are [T, 2F] (row strides ld_ag, ld_dag).  Full 256 x 256
+// tiles only (T % 256 == 0, F % 256 == 0); anything else returns LDM_E_SHAPE and the caller runs the
+// GEMM and ldm_swiglu_bwd separately.
+int ldm_gemm_mfma256_bf16_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
+                                     int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag,
+                                     hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, 0, 0, T, F, K, 1.0f, dy, ld_dy, W, ldw, dag, ld_dag, nullptr, ag, ld_ag);
+  if (rc) return rc;
+  if (T < 256 || T % 256 || F < 256 || F % 256) return LDM_E_SHAPE;
+  if (ld_ag % 8 || ld_dag % 8 || ld_ag < 2 * F || ld_dag < 2 * F || !aligned_to(ag, 16) || !aligned_to(dag, 16)) return LDM_E_ALIGN;
+  const int64_t tm = T / 256, tn = F / 256;
+  if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
+  g.gate_off = F;
+  g.tiles_m = (int)tm;
+  g.tiles_n = (int)tn;
+  return launch256<true, false, 256, bf16_t, 0, 2>(g, s);
 }
 
 // Forms with device-side sizes (see MArgs): used for the LM-head backward over the compacted

@@ -455,6 +455,99 @@ def swiglu_act(ag: Tensor) -> Tensor:
     return _SwiGLUAct.apply(ag)
 
 
+FUSED_SWIGLU_DOWN = os.environ.get("LDM_FUSED_SWIGLU", "1") != "0"   # SwiGLU backward inside the w3 input-gradient GEMM
+
+
+class _SwiGLUDown(torch.autograd.Function):
+    """y = (a * silu(g)) @ W3^T + b (+ residual) for ag = [a | g]: SwiGLU.forward after the two up
+    projections (src/transformer.py:93-95).  Backward never writes the gradient of the hidden
+    activation: dag comes out of the epilogue of the GEMM dy @ W3 (ldm_gemm_swiglu_bwd)."""
+
+    @staticmethod
+    def forward(ctx, ag, residual, pack: PackedWeights, *params):
+        N.require_device(ag)
+        lib = N.lib()
+        w, b = pack.get()
+        dt = pack.dtype
+        F2 = ag.shape[-1]
+        F = F2 // 2
+        ag2 = _rows2d(ag)
+        if ag2.dtype != dt:
+            ag2 = ag2.to(dt)
+        if ag2.stride(0) != F2:
+            ag2 = ag2.contiguous()
+        T = ag2.shape[0]
+        h = torch.empty(T, F, dtype=dt, device=ag2.device)
+        N.check(lib.ldm_swiglu_fwd(ag2.data_ptr(), T, F, N.dtype_code(dt), h.data_ptr(), N.stream()), "ldm_swiglu_fwd")
+        y = torch.empty(T, pack.n_pad, dtype=dt, device=ag2.device)
+        res = None
+        if residual is not None:
+            res = _rows2d(residual)
+            if res.dtype != dt:
+                res = res.to(dt)
+        _gemm(dt, dt, 0, 1, T, pack.n_pad, F, h, F, w, F, y, pack.n_pad, bias=b, res=res,
+              ldr=res.stride(0) if res is not None else 0, tag=pack.name + ".fwd")
+        ctx.pack = pack
+        ctx.res_shape = tuple(residual.shape) if residual is not None else None
+        ctx.out_shape = tuple(ag.shape[:-1]) + (pack.n,)
+        ctx.ag_shape = tuple(ag.shape)
+        ctx.save_for_backward(ag2, h, w)
+        y = y[:, :pack.n] if pack.n != pack.n_pad else y
+        return y.reshape(ctx.out_shape) if y.is_contiguous() else y.view(ctx.out_shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        ag2, h, w = ctx.saved_tensors
+        pack = ctx.pack
+        lib = N.lib()
+        dt = pack.dtype
+        T, F = h.shape
+        n, n_pad = pack.n, pack.n_pad
+        gy2 = gy.reshape(T, n)
+        if gy2.dtype == dt and gy2.stride(-1) == 1 and n_pad == n and (T == 1 or gy2.stride(0) == n_pad):
+            g = gy2
+        else:
+            g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
+            g[:, :n].copy_(gy2)
+        dag = None
+        if ctx.needs_input_grad[0]:
+            dag = torch.empty_like(ag2)
+            rc = -3
+            if dt == torch.bfloat16 and FUSED_SWIGLU_DOWN:
+                rc = lib.ldm_gemm_swiglu_bwd(T, F, n_pad, g.data_ptr(), n_pad, w.data_ptr(), F, ag2.data_ptr(), 2 * F,
+                                             dag.data_ptr(), 2 * F, N.stream())
+                if rc not in (-2, -3):
+                    N.check(rc, "ldm_gemm_swiglu_bwd")
+            if rc in (-2, -3):
+                dh = torch.empty(T, F, dtype=dt, device=g.device)
+                _gemm(dt, dt, 0, 0, T, F, n_pad, g, n_pad, w, F, dh, F, tag=pack.name + ".dx")
+                N.check(lib.ldm_swiglu_bwd(ag2.data_ptr(), dh.data_ptr(), T, F, N.dtype_code(dt), dag.data_ptr(), N.stream()),
+                        "ldm_swiglu_bwd")
+            dag = dag.view(ctx.ag_shape)
+        dwb = ZERO_POOL.take(n_pad * F + n_pad, g.device)
+        dw, db = dwb[:n_pad * F].view(n_pad, F), dwb[n_pad * F:]
+        rc = -2
+        if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
+            rc = lib.ldm_gemm_acc_rowsum(1, 0, n_pad, F, T, 1.0, g.data_ptr(), n_pad, h.data_ptr(), F, dw.data_ptr(), F,
+                                         db.data_ptr(), N.stream())
+            if rc not in (-2, -3):
+                N.check(rc, "ldm_gemm_acc_rowsum")
+        if rc in (-2, -3):
+            N.check(lib.ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, F, T, 1.0, g.data_ptr(), n_pad, h.data_ptr(), F,
+                                     dw.data_ptr(), F, N.stream()), "ldm_gemm_acc")
+            ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
+            N.check(lib.ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
+                                   N.stream()), "ldm_colsum")
+        dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
+        return (dag, dres, None, dw[:n], db[:n])
+
+
+def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None) -> Tensor:
+    """w3(a * silu(g)) (+ residual) for the fused activation ag = [a | g]; one weight in ``pack``."""
+    assert len(pack.weights) == 1
+    return _SwiGLUDown.apply(ag, residual, pack, pack.weights[0], pack.biases[0])
+
+
 # ----------------------------------------------------------------------------
 class _RopeAttention(torch.autograd.Function):
     """RoPE(q,k), q/sqrt(hd), softmax(q k^T + key mask) v on a fused qkv activation."""

@@ -93,8 +93,7 @@ class SwiGLU(nn.Module):
 
     def forward(self, x: Tensor, residual: Tensor | None = None) -> Tensor:
         ag = ops.packed_linear(x, self._pack("in"))
-        hidden = ops.swiglu_act(ag)
-        return ops.packed_linear(hidden, self._pack("out"), residual=residual)
+        return ops.swiglu_down(ag, self._pack("out"), residual=residual)
 
 
 def rotate_half(x: Tensor) -> Tensor:

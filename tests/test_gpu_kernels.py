@@ -527,3 +527,27 @@ def test_fused_adamw_matches_oracle_and_torch(dev):
     # state_dict round trip with torch.optim.AdamW's layout
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("T,F,K", [(256, 256, 64), (512, 512, 768), (8192, 1024, 768), (16384, 768, 96)])
+def test_gemm_swiglu_bwd_epilogue(dev, T, F, K):
+    """ldm_gemm_swiglu_bwd (dag from the epilogue of dy @ W3, hidden gradient never written) against
+    the fp32 composition of src/transformer.py:93 under autograd, and its shape refusals."""
+    from src import _native as N
+    lib = N.lib()
+    torch.manual_seed(T + F)
+    dy = torch.randn(T, K, device=dev).bfloat16()
+    w = (torch.randn(K, F, device=dev) / math.sqrt(K)).bfloat16()
+    ag = torch.randn(T, 2 * F, device=dev).bfloat16()
+    dag = torch.full((T, 2 * F), float("nan"), device=dev, dtype=torch.bfloat16)
+    N.check(lib.ldm_gemm_swiglu_bwd(T, F, K, dy.data_ptr(), K, w.data_ptr(), F, ag.data_ptr(), 2 * F, dag.data_ptr(),
+                                    2 * F, N.stream()), "ldm_gemm_swiglu_bwd")
+    agf = ag.float().requires_grad_(True)
+    a, g = agf[:, :F], agf[:, F:]
+    (a * torch.nn.functional.silu(g)).backward(dy.float() @ w.float())
+    assert rel_err(dag.float(), agf.grad) < 6e-3
+    # shapes the fused form does not take
+    assert lib.ldm_gemm_swiglu_bwd(T + 8, F, K, dy.data_ptr(), K, w.data_ptr(), F, ag.data_ptr(), 2 * F, dag.data_ptr(),
+                                   2 * F, N.stream()) == -3
+    assert lib.ldm_gemm_swiglu_bwd(T, F - 128, K, dy.data_ptr(), K, w.data_ptr(), F, ag.data_ptr(), 2 * F,
+                                   dag.data_ptr(), 2 * F, N.stream()) == -3
