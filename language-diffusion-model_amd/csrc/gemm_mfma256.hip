@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
                 const unsigned aw = av[j >> 1], gw = gv[j >> 1];
                 const float a_ = (j & 1) ? __uint_as_float(aw & 0xffff0000u) : __uint_as_float(aw << 16);
                 const float g_ = (j & 1) ? __uint_as_float(gw & 0xffff0000u) : __uint_as_float(gw << 16);
-                const float sg = 1.0f / (1.0f + __expf(-g_));
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g_));   // 1 ulp; the output is bf16
                 const float dh = o8[j];
                 o8[j] = dh * (g_ * sg);
                 dg8[j] = dh * a_ * sg * (1.0f + g_ * (1.0f - sg));
