@@ -195,10 +195,18 @@ class RotaryMultiheadAttention(nn.Module):
         cos, sin = self.rotary_emb.half_tables(query, seq)
         key_valid = None
         if key_padding_mask is not None:
-            key_valid = (~key_padding_mask.bool()).to(torch.uint8).contiguous()
+            # the model converts the mask once per forward and hangs the result on the tensor
+            key_valid = getattr(key_padding_mask, "_ldm_key_valid", None)
+            if key_valid is None:
+                key_valid = _key_valid_bytes(key_padding_mask)
         qkv = ops.packed_linear(query, self._pack("qkv"))
         attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin)
         return ops.packed_linear(attn, self._pack("out"), residual=residual)
+
+
+def _key_valid_bytes(key_padding_mask: Tensor) -> Tensor:
+    """True-means-padding mask [B,S] -> the uint8 'key is valid' bytes the attention kernels read."""
+    return (~key_padding_mask.bool()).to(torch.uint8).contiguous()
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -283,6 +291,7 @@ class DiffusionTransformer(nn.Module):
         key_padding_mask = None
         if attention_mask is not None:
             key_padding_mask = attention_mask == 0
+            key_padding_mask._ldm_key_valid = _key_valid_bytes(key_padding_mask)   # shared by all layers
         for layer in self.layers:
             x = layer(x, src_key_padding_mask=key_padding_mask)
         return self.norm(x)
