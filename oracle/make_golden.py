@@ -330,11 +330,46 @@ def build_sampling(smp, so, out_dir):
     print("[sampling] oracle == reference on greedy generate, 6 remasking cases and 3 greedy sample loops")
 
 
+SCHEDULE_CASES = [
+    # create_scheduler(total_steps, warmup_steps, initial_lr, peak_lr, stable_lr, final_lr), optimizer lr
+    dict(total_steps=100, warmup_steps=10, initial_lr=0.0, peak_lr=None, stable_lr=None, final_lr=None, lr=5e-4),
+    dict(total_steps=37, warmup_steps=2000, initial_lr=0.0, peak_lr=None, stable_lr=None, final_lr=None, lr=5e-4),
+    dict(total_steps=64, warmup_steps=0, initial_lr=0.0, peak_lr=4e-4, stable_lr=1e-4, final_lr=1e-5, lr=1e-3),
+    dict(total_steps=3, warmup_steps=1, initial_lr=1e-6, peak_lr=None, stable_lr=None, final_lr=None, lr=3e-4),
+    dict(total_steps=1000, warmup_steps=333, initial_lr=1e-5, peak_lr=4e-4, stable_lr=None, final_lr=1e-7, lr=2e-4),
+]
+
+
+def build_schedule(out_dir):
+    """Learning rates the reference's create_scheduler / WarmupStableDecayLR (src/scheduler.py:11-159)
+    hand the optimizer, step by step, for a few splits (incl. a warmup longer than the run and
+    phases of zero length), 20 % past the end of the run."""
+    from src.scheduler import create_scheduler
+
+    out = {"n_cases": np.array([len(SCHEDULE_CASES)])}
+    for j, c in enumerate(SCHEDULE_CASES):
+        w = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.SGD([w], lr=c["lr"])
+        sch = create_scheduler(opt, **{k: v for k, v in c.items() if k != "lr"})
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(c["total_steps"] + c["total_steps"] // 5 + 2):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        out[f"s{j}_lrs"] = np.array(lrs, dtype=np.float64)
+        out[f"s{j}_phases"] = np.array([sch.warmup_steps, sch.stable_steps, sch.middle_decay_steps,
+                                        sch.final_decay_steps], dtype=np.int64)
+        out[f"s{j}_levels"] = np.array([sch.initial_lr, sch.peak_lr, sch.stable_lr, sch.final_lr], dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir, "schedule.npz"), **out)
+    print(f"[schedule] {len(SCHEDULE_CASES)} learning-rate curves recorded from the reference")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--only-sampling", action="store_true", help="rewrite sampling.npz only")
+    ap.add_argument("--only-schedule", action="store_true", help="rewrite schedule.npz only")
     args = ap.parse_args()
     so = _load_oracle()
     # the reference's package is called ``src``; import it from ITS checkout
@@ -345,8 +380,12 @@ def main():
     if "--only-sampling" in sys.argv:
         build_sampling(smp, so, args.out)
         return
+    if args.only_schedule:
+        build_schedule(args.out)
+        return
     build_masking(so, args.out)
     build_loss(so, args.out)
+    build_schedule(args.out)
     build_sampling(smp, so, args.out)
     build_case(None, so, "c1_tiny", d=32, H=4, L=2, Fd=64, V=200, B=3, S=10, t=0.6, seed=42,
                ragged=True, dirty=True, out_dir=args.out)

@@ -307,11 +307,13 @@ def test_full_size_model_properties(dev):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_with_fused_adamw_tracks_torch_adamw(dev, dtype):
     """Four trainer steps with src.optim.FusedAdamW (weight copies refreshed inside the update) and
-    with torch.optim.AdamW (copies re-cast by the next forward) from the same start, same masks."""
+    with torch.optim.AdamW (copies re-cast by the next forward) from the same start, same masks,
+    both under the warmup-stable-decay schedule (a different learning rate every step)."""
     import random
 
     from src.dp import HipAccelerator
     from src.optim import FusedAdamW
+    from src.scheduler import create_scheduler
     from src.trainer import DiffusionLanguageModelTrainer
     g = load_golden("step_hd96.npz")
     ids = torch.from_numpy(g["input_ids"]).to(dev)
@@ -325,10 +327,16 @@ def test_training_with_fused_adamw_tracks_torch_adamw(dev, dtype):
             opt = acc.prepare(FusedAdamW(model.parameters(), lr=5e-4, weight_decay=0.1))
         else:
             opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1)
-        trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+        sched = create_scheduler(opt, total_steps=4, warmup_steps=2, initial_lr=1e-4)
+        trainer = DiffusionLanguageModelTrainer(model, opt, sched, acc)
         random.seed(1)
         torch.manual_seed(1)
-        losses = [trainer.loss_value(trainer._step({"input_ids": ids, "attention_mask": att})) for _ in range(4)]
+        losses, lrs = [], []
+        for _ in range(4):
+            lrs.append(opt.param_groups[0]["lr"])
+            losses.append(trainer.loss_value(trainer._step({"input_ids": ids, "attention_mask": att})))
+            sched.step()          # per optimizer step, as the reference's train() does (src/trainer.py:137-138)
+        assert lrs[0] == 1e-4 and lrs[2] == 5e-4 and len(set(lrs)) >= 3, lrs
         finals.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}, model))
     (l_hip, p_hip, m_hip), (l_t, p_t, _) = finals
     tol = 1e-5 if dtype == torch.float32 else 2e-2

@@ -111,3 +111,41 @@ def test_fused_adamw_refuses_host_tensors():
         opt.step()
     with pytest.raises(ValueError):
         FusedAdamW([p], lr=-1.0)
+
+
+def test_learning_rate_schedule_matches_reference_curves():
+    """Bit-exact against curves recorded from the reference's create_scheduler (src/scheduler.py:97-159);
+    the cases are those of oracle/make_golden.py::SCHEDULE_CASES."""
+    from src.scheduler import WarmupStableDecayLR, create_scheduler
+    cases = [
+        dict(total_steps=100, warmup_steps=10, initial_lr=0.0, peak_lr=None, stable_lr=None, final_lr=None, lr=5e-4),
+        dict(total_steps=37, warmup_steps=2000, initial_lr=0.0, peak_lr=None, stable_lr=None, final_lr=None, lr=5e-4),
+        dict(total_steps=64, warmup_steps=0, initial_lr=0.0, peak_lr=4e-4, stable_lr=1e-4, final_lr=1e-5, lr=1e-3),
+        dict(total_steps=3, warmup_steps=1, initial_lr=1e-6, peak_lr=None, stable_lr=None, final_lr=None, lr=3e-4),
+        dict(total_steps=1000, warmup_steps=333, initial_lr=1e-5, peak_lr=4e-4, stable_lr=None, final_lr=1e-7, lr=2e-4),
+    ]
+    g = load_golden("schedule.npz")
+    assert int(g["n_cases"][0]) == len(cases)
+    for j, c in enumerate(cases):
+        w = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.SGD([w], lr=c["lr"])
+        sch = create_scheduler(opt, **{k: v for k, v in c.items() if k != "lr"})
+        assert isinstance(sch, WarmupStableDecayLR)
+        assert [sch.warmup_steps, sch.stable_steps, sch.middle_decay_steps, sch.final_decay_steps] == \
+            [int(x) for x in g[f"s{j}_phases"]]
+        assert [sch.initial_lr, sch.peak_lr, sch.stable_lr, sch.final_lr] == [float(x) for x in g[f"s{j}_levels"]]
+        want = g[f"s{j}_lrs"]
+        got = [opt.param_groups[0]["lr"]]
+        for _ in range(len(want) - 1):
+            opt.step()
+            sch.step()
+            got.append(opt.param_groups[0]["lr"])
+        assert np.array_equal(np.array(got, dtype=np.float64), want), (j, got[:5], want[:5])
+    # the state dict carries the reference's attribute names, so checkpoints move between the two
+    keys = set(sch.state_dict())
+    assert {"warmup_steps", "stable_steps", "middle_decay_steps", "final_decay_steps", "phase2_start",
+            "phase3_start", "phase4_start", "phase5_start", "initial_lr", "peak_lr", "stable_lr", "final_lr",
+            "last_epoch", "base_lrs"} <= keys
+    sch2 = create_scheduler(torch.optim.SGD([w], lr=1.0), total_steps=10)
+    sch2.load_state_dict(sch.state_dict())
+    assert sch2.lr_at(500) == sch.lr_at(500)
