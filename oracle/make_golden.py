@@ -364,12 +364,76 @@ def build_schedule(out_dir):
     print(f"[schedule] {len(SCHEDULE_CASES)} learning-rate curves recorded from the reference")
 
 
+class WordHashTokenizer:
+    """Stand-in for the reference's tokenizer wrapper, whose vocabulary needs a download: BOS, one id
+    per whitespace-separated word (a hash of its bytes into [1000, 30522)), EOS, cut to
+    ``max_length``.  Same class in tests/test_host_logic.py."""
+
+    def encode(self, text, max_length=512, return_tensors=False):
+        ids = [101]
+        for w in text.split():
+            h = 2166136261
+            for b in w.encode("utf-8"):
+                h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+            ids.append(1000 + h % (30522 - 1000))
+        ids = ids[:max_length - 1] + [102]
+        return {"input_ids": ids, "attention_mask": [1] * len(ids)}
+
+
+DATASET_LINES = [
+    "q1@@what is the capital of france@@paris",
+    "",
+    "no delimiter on this line",
+    "q2@@how many legs does a spider have",
+    "   q3@@why@@because@@really   ",
+    "q4@@" + " ".join(f"w{i}" for i in range(40)),
+    "q5@@",
+    "q6@@name three primary colours please@@red green blue",
+    "q7@@who wrote hamlet",
+    "q8@@is water wet",
+    "q9@@a b c d e f g",
+    "q10@@last one here",
+]
+
+
+def build_dataset(out_dir):
+    """The reference's QuestionDataset / collate_batch / create_question_dataloaders
+    (src/dataset.py:26-202) over a 12-line file and the stand-in tokenizer: the parsed questions,
+    every item, and the train / validation batches drawn after torch.manual_seed(3)."""
+    import tempfile
+
+    from src.dataset import QuestionDataset, create_question_dataloaders
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "questions.txt")
+        with open(path, "w", encoding="utf-8") as f:
+            f.write("\n".join(DATASET_LINES) + "\n")
+        tok = WordHashTokenizer()
+        ds = QuestionDataset(path, tok, max_length=16)
+        out = {"lines": np.array(DATASET_LINES), "questions": np.array(ds.questions), "n_items": np.array([len(ds)])}
+        for i in range(len(ds)):
+            out[f"item{i}_ids"] = ds[i]["input_ids"].numpy()
+        torch.manual_seed(3)
+        tr, va = create_question_dataloaders(path, tok, batch_size=4, max_length=16, train_ratio=0.75,
+                                             shuffle=True, num_workers=0)
+        for name, dl in (("train", tr), ("val", va)):
+            n = 0
+            for b in dl:
+                out[f"{name}{n}_ids"] = b["input_ids"].numpy()
+                out[f"{name}{n}_mask"] = b["attention_mask"].numpy()
+                n += 1
+            out[f"n_{name}"] = np.array([n])
+    np.savez_compressed(os.path.join(out_dir, "dataset.npz"), **out)
+    print(f"[dataset] {len(ds)} questions, {int(out['n_train'][0])} train + {int(out['n_val'][0])} validation batches recorded")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--only-sampling", action="store_true", help="rewrite sampling.npz only")
     ap.add_argument("--only-schedule", action="store_true", help="rewrite schedule.npz only")
+    ap.add_argument("--only-dataset", action="store_true", help="rewrite dataset.npz only")
     args = ap.parse_args()
     so = _load_oracle()
     # the reference's package is called ``src``; import it from ITS checkout
@@ -383,9 +447,13 @@ def main():
     if args.only_schedule:
         build_schedule(args.out)
         return
+    if args.only_dataset:
+        build_dataset(args.out)
+        return
     build_masking(so, args.out)
     build_loss(so, args.out)
     build_schedule(args.out)
+    build_dataset(args.out)
     build_sampling(smp, so, args.out)
     build_case(None, so, "c1_tiny", d=32, H=4, L=2, Fd=64, V=200, B=3, S=10, t=0.6, seed=42,
                ragged=True, dirty=True, out_dir=args.out)

@@ -93,3 +93,25 @@ def test_training_step_on_ragged_device_batches(dev):
     batches = SyntheticTokenBatches(4, 8, 96, 2000, seed=5, device=dev, id_lo=200, min_len=10)
     loss = trainer.train_epoch(batches)
     assert np.isfinite(loss) and trainer.global_step == 4
+
+
+def test_question_loaders_with_device_padding_match_reference_batches(dev, tmp_path):
+    """create_question_dataloaders(device=...) -- items un-collated from the workers, padded by
+    ldm_collate_pad in HBM -- yields the batches recorded from the reference's host loaders
+    (src/dataset.py:137-202) for the same file, tokenizer stand-in and seed."""
+    from conftest import load_golden
+    from test_host_logic import WordHashTokenizer, write_question_file
+    from src.dataset import create_question_dataloaders
+    g = load_golden("dataset.npz")
+    path = write_question_file(tmp_path, g)
+    torch.manual_seed(3)
+    tr, va = create_question_dataloaders(path, WordHashTokenizer(), batch_size=4, max_length=16, train_ratio=0.75,
+                                         shuffle=True, num_workers=0, device=dev)
+    for name, dl in (("train", tr), ("val", va)):
+        assert len(dl) == int(g[f"n_{name}"][0])
+        batches = list(dl)
+        assert len(batches) == int(g[f"n_{name}"][0])
+        for n, b in enumerate(batches):
+            assert b["input_ids"].is_cuda and b["input_ids"].dtype == torch.int64
+            assert np.array_equal(b["input_ids"].cpu().numpy(), g[f"{name}{n}_ids"])
+            assert np.array_equal(b["attention_mask"].cpu().numpy(), g[f"{name}{n}_mask"])

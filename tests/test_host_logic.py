@@ -149,3 +149,55 @@ def test_learning_rate_schedule_matches_reference_curves():
     sch2 = create_scheduler(torch.optim.SGD([w], lr=1.0), total_steps=10)
     sch2.load_state_dict(sch.state_dict())
     assert sch2.lr_at(500) == sch.lr_at(500)
+
+
+class WordHashTokenizer:
+    """Stand-in for the reference's tokenizer wrapper (same class as in oracle/make_golden.py)."""
+
+    def encode(self, text, max_length=512, return_tensors=False):
+        ids = [101]
+        for w in text.split():
+            h = 2166136261
+            for b in w.encode("utf-8"):
+                h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+            ids.append(1000 + h % (30522 - 1000))
+        ids = ids[:max_length - 1] + [102]
+        return {"input_ids": ids, "attention_mask": [1] * len(ids)}
+
+
+def write_question_file(tmp_path, g):
+    path = tmp_path / "questions.txt"
+    path.write_text("\n".join(str(x) for x in g["lines"]) + "\n", encoding="utf-8")
+    return str(path)
+
+
+def test_question_dataset_and_loaders_match_reference_batches(tmp_path):
+    """Parsing, items, split and padded batches equal those recorded from the reference's
+    src/dataset.py over the same file, tokenizer stand-in and seed."""
+    from src.dataset import QuestionDataset, collate_batch, create_question_dataloaders
+    g = load_golden("dataset.npz")
+    path = write_question_file(tmp_path, g)
+    ds = QuestionDataset(path, WordHashTokenizer(), max_length=16)
+    assert ds.questions == [str(x) for x in g["questions"]] and len(ds) == int(g["n_items"][0])
+    for i in range(len(ds)):
+        item = ds[i]
+        assert item["input_ids"].dtype == torch.long and item["input_ids"].dim() == 1
+        assert np.array_equal(item["input_ids"].numpy(), g[f"item{i}_ids"])
+        assert item["attention_mask"].tolist() == [1] * item["input_ids"].numel()
+    assert QuestionDataset(path, WordHashTokenizer(), transform=lambda it: {**it, "extra": 1})[0]["extra"] == 1
+    torch.manual_seed(3)
+    tr, va = create_question_dataloaders(path, WordHashTokenizer(), batch_size=4, max_length=16, train_ratio=0.75,
+                                         shuffle=True, num_workers=0)
+    for name, dl in (("train", tr), ("val", va)):
+        batches = list(dl)
+        assert len(batches) == int(g[f"n_{name}"][0])
+        for n, b in enumerate(batches):
+            assert np.array_equal(b["input_ids"].numpy(), g[f"{name}{n}_ids"])
+            assert np.array_equal(b["attention_mask"].numpy(), g[f"{name}{n}_mask"])
+    _, none = create_question_dataloaders(path, WordHashTokenizer(), train_ratio=1.0, num_workers=0)
+    assert none is None
+    # collate_batch against torch's pad_sequence on ragged items
+    items = [{"input_ids": torch.arange(1, n + 1), "attention_mask": torch.ones(n, dtype=torch.long)} for n in (3, 7, 1)]
+    out = collate_batch(items)
+    for k in ("input_ids", "attention_mask"):
+        assert torch.equal(out[k], torch.nn.utils.rnn.pad_sequence([it[k] for it in items], batch_first=True))
