@@ -350,11 +350,16 @@ __global__ __launch_bounds__(256) void rope_qk_k(T *qkv, int64_t rows, int64_t s
 
 // 8-pair form (hd/2 a multiple of 8): a thread rotates 8 consecutive elements with their partners
 // hd/2 further on, 16-byte accesses for bf16.  A workgroup walks groups of RG consecutive rows;
-// inside a group the (row, q|k, head, vector) items are spread flat over the threads.
+// inside a group the (row, q|k, head, vector) items are spread flat over the threads.  The two
+// divisions that take an item index apart are multiplications by ceil(2^32 / divisor) (m_row,
+// m_vph; exact while index * divisor < 2^32, which the launcher checks; m_vph == 0 stands for a
+// divisor of 1), and the position in the sequence is carried from the group's first row: integer
+// division by a run-time value costs more VALU time than the rotation itself.
 template <typename T, int RG>
 __global__ __launch_bounds__(256) void rope_qk8_k(T *__restrict__ qkv, int rows, int seq, int nhead, int hd,
                                                   int64_t ld, const float *__restrict__ cos_t,
-                                                  const float *__restrict__ sin_t, float q_scale, int inverse) {
+                                                  const float *__restrict__ sin_t, float q_scale, int inverse,
+                                                  unsigned m_row, unsigned m_vph) {
   const int half = hd >> 1;
   const unsigned vph = (unsigned)half >> 3;               // vectors per head half
   const unsigned per_head_set = (unsigned)nhead * vph;    // items of the q (or k) heads of one row
@@ -364,15 +369,17 @@ __global__ __launch_bounds__(256) void rope_qk8_k(T *__restrict__ qkv, int rows,
     const int row0 = g * RG;
     const int nr = rows - row0 < RG ? rows - row0 : RG;
     const unsigned items = (unsigned)nr * per_row;
+    const int pos0 = row0 % seq;
     for (unsigned it = threadIdx.x; it < items; it += 256) {
-      const unsigned lr = it / per_row;
+      const unsigned lr = __umulhi(it, m_row);
       unsigned rem = it - lr * per_row;
       const unsigned which = rem >= per_head_set ? 1u : 0u;
       rem -= which * per_head_set;
-      const unsigned h = rem / vph;
+      const unsigned h = m_vph ? __umulhi(rem, m_vph) : rem;
       const unsigned i0 = (rem - h * vph) * 8u;
       const int row = row0 + (int)lr;
-      const int pos = row % seq;
+      int pos = pos0 + (int)lr;
+      while (pos >= seq) pos -= seq;
       T *p = qkv + (int64_t)row * ld + (int64_t)which * nhead * hd + (int64_t)h * hd + i0;
       Raw8<T> a, b;
       a.load(p);
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd8_k(const T *__restrict__ ag, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float g = g0.get(j);
-        const float sg = 1.0f / (1.0f + __expf(-g));
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
         o[j] = a0.get(j) * (g * sg);
       }
       Raw8<T>::store(hr + v0 * 8, o);
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd8_k(const T *__restrict__ ag, i
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float g = g1.get(j);
-          const float sg = 1.0f / (1.0f + __expf(-g));
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
           o[j] = a1.get(j) * (g * sg);
         }
         Raw8<T>::store(hr + v1 * 8, o);
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd8_k(const T *__restrict__ ag, c
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float g = g0.get(j), d = d0.get(j);
-        const float sg = 1.0f / (1.0f + __expf(-g));
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
         da[j] = d * (g * sg);
         dg[j] = d * a0.get(j) * sg * (1.0f + g * (1.0f - sg));
       }
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd8_k(const T *__restrict__ ag, c
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float g = g1.get(j), d = d1.get(j);
-          const float sg = 1.0f / (1.0f + __expf(-g));
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
           da[j] = d * (g * sg);
           dg[j] = d * a1.get(j) * sg * (1.0f + g * (1.0f - sg));
         }
@@ -823,13 +830,17 @@ extern "C" int ldm_rope_qk(void *qkv, int dtype, int64_t batch, int64_t seq, int
                    aligned_to(sin_t, 16) && ((half * esz) % (4 * esz) == 0);
   if (dtype != LDM_F32 && dtype != LDM_BF16) return LDM_E_DTYPE;
   if (vec && half % 8 == 0 && ld % 8 == 0 && (nhead * hd) % 8 == 0 && rows < (1 << 30) && seq < (1 << 30) &&
-      2 * nhead * (half / 8) <= (1 << 20)) {
+      2 * nhead * (half / 8) <= (1 << 12)) {
     constexpr int RG = 8;
     const unsigned grid = stream_grid(ceil_div(rows, RG), 1);
+    // ceil(2^32 / d): floor(n / d) == umulhi(n, that) for n * d < 2^32 (here n < RG * per_row <= 2^15)
+    const uint64_t per_row = 2 * (uint64_t)nhead * (half / 8), vph = half / 8;
+    const unsigned m_row = (unsigned)(((1ull << 32) + per_row - 1) / per_row);
+    const unsigned m_vph = vph == 1 ? 0u : (unsigned)(((1ull << 32) + vph - 1) / vph);
     if (dtype == LDM_F32)
-      hipLaunchKernelGGL((rope_qk8_k<float, RG>), dim3(grid), dim3(256), 0, s, (float *)qkv, (int)rows, (int)seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+      hipLaunchKernelGGL((rope_qk8_k<float, RG>), dim3(grid), dim3(256), 0, s, (float *)qkv, (int)rows, (int)seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse, m_row, m_vph);
     else
-      hipLaunchKernelGGL((rope_qk8_k<bf16_t, RG>), dim3(grid), dim3(256), 0, s, (bf16_t *)qkv, (int)rows, (int)seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse);
+      hipLaunchKernelGGL((rope_qk8_k<bf16_t, RG>), dim3(grid), dim3(256), 0, s, (bf16_t *)qkv, (int)rows, (int)seq, (int)nhead, (int)hd, ld, cos_t, sin_t, q_scale, inverse, m_row, m_vph);
   } else if (vec) {
     const unsigned grid = stream_grid(rows * 2 * nhead * (half / 4), 256);
     if (dtype == LDM_F32)
