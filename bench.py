@@ -9,7 +9,7 @@ zero_grad -> forward masking -> transformer forward -> masked CE -> backward (wi
 RCCL gradient all-reduce when N > 1) -> AdamW.step -> loss.item(), on synthetic tokens that are
 resident in HBM before the timed region.  Workload: the reference's configs/default.yaml model
 (d=768, 8 heads of 96, 8 layers, ff=1024, vocab 30522) at sequence length 512, bf16 compute,
-dropout 0.0, per-GPU batch --batch (default 512 sequences, the YAML's own batch_size, = 262,144 tokens per
+dropout 0.0 (--dropout), per-GPU batch --batch (default 512 sequences, the YAML's own batch_size, = 262,144 tokens per
 GPU per step; weak scaling).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="residual dropout probability (the two per-layer residual dropouts; the fused "
+                         "attention kernel applies none to the attention probabilities)")
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
                     help="hip: src.optim.FusedAdamW (one HIP pass, weight copies refreshed in it); torch: torch.optim.AdamW(fused=True)")
@@ -138,7 +141,7 @@ def main():
     cfg = CONFIGS[args.config]
     torch.manual_seed(42)
     random.seed(42)     # the reference seeds both identically on every rank (main.py:39-40)
-    tr = DiffusionTransformer(DiffusionTransformerConfig(dropout=0.0, layer_norm_eps=1e-12,
+    tr = DiffusionTransformer(DiffusionTransformerConfig(dropout=args.dropout, layer_norm_eps=1e-12,
                                                          max_position_embeddings=max(512, args.seq), **cfg))
     tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
     model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
@@ -218,7 +221,7 @@ def main():
             "config": {"workload": f"configs/default.yaml model, seq {args.seq}" if args.config == "default"
                        else f"{args.config} model, seq {args.seq}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": args.seq,
-                       "parallelism": f"dp{world}", "dropout": 0.0, "optimizer": "AdamW(lr=5e-4, wd=0.1)",
+                       "parallelism": f"dp{world}", "dropout": args.dropout, "optimizer": "AdamW(lr=5e-4, wd=0.1)",
                        **cfg},
             "loss_last_step": last,
             "train_flops_per_token": fpt,
