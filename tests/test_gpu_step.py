@@ -288,6 +288,12 @@ def test_full_size_model_properties(dev):
     assert math.isfinite(lf) and 8.0 < lf < 13.0            # ~ln(30522) = 10.3 at random init
     assert abs(lf - ld) <= 1e-5 * abs(ld)
     for n in gd:
+        if n.endswith("k_proj.bias"):
+            # mathematically zero (softmax is invariant to a shift of all keys): both runs hold
+            # rounding noise here, whose order of summation (float atomics) differs from run to run
+            scale = float(gd[n.replace("k_proj", "q_proj")].abs().max())
+            assert float((gf[n] - gd[n]).abs().max()) < 2e-2 * scale, n
+            continue
         assert rel_err(gf[n], gd[n]) < 5e-3, n
     # (3) ids absent from the masked input: exactly zero embedding gradient
     torch.manual_seed(99)
