@@ -186,6 +186,22 @@ int ldm_attn_bwd_unrope(int dtype, const void *qkv, int64_t ld_qkv, const uint8_
                         int64_t batch, int64_t nhead, int64_t seq, int64_t hd, const void *o,
                         const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
                         const float *cos_t, const float *sin_t, float q_scale, void *stream);
+/* The same with dropout on the attention probabilities, `attn_weights = self.dropout(attn_weights)`
+ * (src/transformer.py:278): O = (mask * softmax / (1 - p)) v.  Element (batch*head, query, key) is
+ * kept iff a 32-bit hash of (seed, its coordinates) is >= round(p * 2^32) (csrc/common.h), so the
+ * backward regenerates the forward's mask from (p, seed) and nothing is stored; p in [0, 1), p == 0
+ * is ldm_attn_fwd / ldm_attn_bwd exactly.  The reference draws its mask from torch's generator: the
+ * two masks agree in distribution, not element by element.
+ * ws: F32 forward needs ldm_attn_bwd_ws_bytes() of scratch (NULL for BF16).  Backward: cos_t / sin_t
+ * both NULL, or both given to fuse the rotary backward as ldm_attn_bwd_unrope does. */
+int ldm_attn_fwd_dropout(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                         int64_t batch, int64_t nhead, int64_t seq, int64_t hd, void *o, int64_t ld_o,
+                         void *saved, void *ws, float p, uint64_t seed, void *stream);
+int ldm_attn_bwd_dropout(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                         int64_t batch, int64_t nhead, int64_t seq, int64_t hd, const void *o,
+                         const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
+                         const float *cos_t, const float *sin_t, float q_scale, float p, uint64_t seed,
+                         void *stream);
 
 /* ---------------------------------------------------------------- K4: masked cross-entropy
  * masked_cross_entropy_loss / variational_lower_bound_loss (src/loss.py:8-65).

@@ -49,6 +49,8 @@ struct FArgs {
   // optional (backward): fp32 [S, hd/2] rotary tables; dq and dk are then written as gradients
   // w.r.t. the PRE-rotation q and k (dq also multiplied by rope_scale, the factor q was scaled by)
   const float *rope_cos, *rope_sin; float rope_scale;
+  // attention-probability dropout (0 = none): keep threshold, 1/(1-p), seed halves (see common.h)
+  unsigned drop_thresh; float drop_inv; unsigned seed_lo, seed_hi;
 };
 
 // Experiment builds (-DLDM_ATTN_TIMING): cycle totals of the forward kernel's per-tile segments of
@@ -247,7 +249,7 @@ __device__ __forceinline__ void unrope_acc(f16_t (&acc)[AT<DP>::ND], float scale
 }
 
 // --------------------------------------------------------------------------- forward
-template <int DP>
+template <int DP, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
+  const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
 
   const int nt = (S + 63) / 64;
   uint4 kr[T::NCH], vr[T::NCH];
@@ -353,6 +356,14 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
         ps += p;
       }
     lsum = lsum * alpha + ps;
+    if constexpr (DROP) {   // the row sum above is that of the undropped softmax
+      const unsigned kb0 = (unsigned)(k0 + 4 * half);
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sacc[kbk][r] = ldm_drop_keep(drop_row, kb0 + kbk * 32 + acc_row(r), a.drop_thresh) ? sacc[kbk][r] * a.drop_inv : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < T::ND; ++i)
 #pragma unroll
@@ -506,7 +517,7 @@ __device__ __forceinline__ unsigned lds_off(const void *p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-template <int DP>
+template <int DP, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
@@ -540,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
+  const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
 
 #ifdef LDM_ATTN_TIMING
   unsigned long long ta[6] = {0, 0, 0, 0, 0, 0}, tk0, tk1, tb = 0;
@@ -623,6 +635,14 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
         ps += p;
       }
     lsum = lsum * alpha + ps;
+    if constexpr (DROP) {   // the row sum above is that of the undropped softmax
+      const unsigned kb0 = (unsigned)(k0 + 4 * half);
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sacc[kbk][r] = ldm_drop_keep(drop_row, kb0 + kbk * 32 + acc_row(r), a.drop_thresh) ? sacc[kbk][r] * a.drop_inv : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < T::ND; ++i)
 #pragma unroll
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
 }
 
 // --------------------------------------------------------------------------- dQ, LDS-DMA tiles
-template <int DP>
+template <int DP, bool DROP>
 __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs a) {
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
@@ -716,6 +736,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
     for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
+  const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
   const float nlse = -a.lse_in[stat] * LOG2E;
   if (half == 0 && q < S) a.delta[stat] = dlt;
@@ -769,7 +790,10 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
       for (int r = 0; r < 16; ++r) {
         const bool ok = (vs >> (kbk * 32 + acc_row(r))) & 1ull;
         const float p = ok ? fast_exp2(fmaf(sacc[r], LOG2E, nlse)) : 0.f;
-        ds[r] = p * (dpacc[r] - dlt);
+        if constexpr (DROP)
+          ds[r] = p * ((ldm_drop_keep(drop_row, (unsigned)(k0 + 4 * half + kbk * 32 + acc_row(r)), a.drop_thresh) ? dpacc[r] * a.drop_inv : 0.f) - dlt);
+        else
+          ds[r] = p * (dpacc[r] - dlt);
       }
       const bf8_t dsf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
@@ -802,7 +826,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 // --------------------------------------------------------------------------- dK, dV, LDS-DMA tiles
 // Q and dO tiles and the two per-row statistics (lse, delta: 64 floats each, one 4-byte LDS-DMA
 // instruction of wave 0 / wave 1) land in one of two buffers; one barrier per tile.
-template <int DP>
+template <int DP, bool DROP>
 __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs a) {
   using T = AT<DP>;
   constexpr int BUF = 2 * Lay<DP>::TILE + 512;
@@ -821,6 +845,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
   bool key_ok = key < S;
   if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
   const int keyc = key < S ? key : S - 1;
+  const unsigned drop_bh = DROP ? ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)) : 0u;
   const int64_t stat0 = ((int64_t)b * a.H + head) * S;
 
   TrAddr<DP> ta[T::ND];
@@ -869,13 +894,19 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
       f16_t sacc, dpacc;
+      [[maybe_unused]] float nd[16];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const float4 l4 = *reinterpret_cast<const float4 *>(lse_s + qbk * 32 + 8 * r4 + 4 * half);
         const float4 d4 = *reinterpret_cast<const float4 *>(dlt_s + qbk * 32 + 8 * r4 + 4 * half);
         sacc[4 * r4 + 0] = -l4.x * LOG2E; sacc[4 * r4 + 1] = -l4.y * LOG2E;
         sacc[4 * r4 + 2] = -l4.z * LOG2E; sacc[4 * r4 + 3] = -l4.w * LOG2E;
-        dpacc[4 * r4 + 0] = -d4.x; dpacc[4 * r4 + 1] = -d4.y; dpacc[4 * r4 + 2] = -d4.z; dpacc[4 * r4 + 3] = -d4.w;
+        if constexpr (DROP) {   // the mask applies to dP alone: -delta is added after the products
+          nd[4 * r4 + 0] = -d4.x; nd[4 * r4 + 1] = -d4.y; nd[4 * r4 + 2] = -d4.z; nd[4 * r4 + 3] = -d4.w;
+          dpacc[4 * r4 + 0] = 0.f; dpacc[4 * r4 + 1] = 0.f; dpacc[4 * r4 + 2] = 0.f; dpacc[4 * r4 + 3] = 0.f;
+        } else {
+          dpacc[4 * r4 + 0] = -d4.x; dpacc[4 * r4 + 1] = -d4.y; dpacc[4 * r4 + 2] = -d4.z; dpacc[4 * r4 + 3] = -d4.w;
+        }
       }
       f16_t s0;
 #pragma unroll
@@ -899,8 +930,15 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pr = key_ok ? fast_exp2(fmaf(s0[r], LOG2E, sacc[r])) : 0.f;
-        p[r] = pr;
-        ds[r] = pr * dpacc[r];
+        if constexpr (DROP) {
+          const unsigned qi = (unsigned)(t * 64 + qbk * 32 + acc_row(r) + 4 * half);
+          const bool keep = ldm_drop_keep(ldm_drop_row(drop_bh, a.seed_hi, qi), (unsigned)key, a.drop_thresh);
+          p[r] = keep ? pr * a.drop_inv : 0.f;
+          ds[r] = pr * ((keep ? dpacc[r] * a.drop_inv : 0.f) + nd[r]);
+        } else {
+          p[r] = pr;
+          ds[r] = pr * dpacc[r];
+        }
       }
       if (lim < 64) {   // workgroup-uniform: the last, partial tile
 #pragma unroll
@@ -942,7 +980,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 }
 
 // --------------------------------------------------------------------------- dQ
-template <int DP>
+template <int DP, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -974,6 +1012,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
     for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
+  const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
   const float nlse = -a.lse_in[stat] * LOG2E;
   if (half == 0 && q < S) a.delta[stat] = dlt;
@@ -1017,7 +1056,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
       for (int r = 0; r < 16; ++r) {
         const bool ok = (vs >> (kbk * 32 + acc_row(r))) & 1ull;
         const float p = ok ? fast_exp2(fmaf(sacc[r], LOG2E, nlse)) : 0.f;
-        ds[r] = p * (dpacc[r] - dlt);
+        if constexpr (DROP)
+          ds[r] = p * ((ldm_drop_keep(drop_row, (unsigned)(k0 + 4 * half + kbk * 32 + acc_row(r)), a.drop_thresh) ? dpacc[r] * a.drop_inv : 0.f) - dlt);
+        else
+          ds[r] = p * (dpacc[r] - dlt);
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -1047,7 +1089,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
 }
 
 // --------------------------------------------------------------------------- dK, dV
-template <int DP>
+template <int DP, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1068,6 +1110,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
   bool key_ok = key < S;
   if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
   const int keyc = key < S ? key : S - 1;
+  const unsigned drop_bh = DROP ? ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)) : 0u;
 
   bf8_t kf[T::NK], vf[T::NK];
 #pragma unroll
@@ -1112,12 +1155,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
       f16_t sacc, dpacc;
+      [[maybe_unused]] float nd[16];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const float4 l4 = *reinterpret_cast<const float4 *>(lse_s + qbk * 32 + 8 * r4 + 4 * half);
         const float4 d4 = *reinterpret_cast<const float4 *>(dlt_s + qbk * 32 + 8 * r4 + 4 * half);
         sacc[4 * r4 + 0] = l4.x; sacc[4 * r4 + 1] = l4.y; sacc[4 * r4 + 2] = l4.z; sacc[4 * r4 + 3] = l4.w;
-        dpacc[4 * r4 + 0] = d4.x; dpacc[4 * r4 + 1] = d4.y; dpacc[4 * r4 + 2] = d4.z; dpacc[4 * r4 + 3] = d4.w;
+        if constexpr (DROP) {   // the mask applies to dP alone: -delta is added after the products
+          nd[4 * r4 + 0] = d4.x; nd[4 * r4 + 1] = d4.y; nd[4 * r4 + 2] = d4.z; nd[4 * r4 + 3] = d4.w;
+          dpacc[4 * r4 + 0] = 0.f; dpacc[4 * r4 + 1] = 0.f; dpacc[4 * r4 + 2] = 0.f; dpacc[4 * r4 + 3] = 0.f;
+        } else {
+          dpacc[4 * r4 + 0] = d4.x; dpacc[4 * r4 + 1] = d4.y; dpacc[4 * r4 + 2] = d4.z; dpacc[4 * r4 + 3] = d4.w;
+        }
       }
       // sacc holds the row constants -lse*log2e; dpacc starts at -delta so that the
       // MFMA chain leaves dP - delta.
@@ -1133,8 +1182,15 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pr = key_ok ? fast_exp2(fmaf(s0[r], LOG2E, sacc[r])) : 0.f;
-        p[r] = pr;
-        ds[r] = pr * dpacc[r];
+        if constexpr (DROP) {
+          const unsigned qi = (unsigned)(t * 64 + qbk * 32 + acc_row(r) + 4 * half);
+          const bool keep = ldm_drop_keep(ldm_drop_row(drop_bh, a.seed_hi, qi), (unsigned)key, a.drop_thresh);
+          p[r] = keep ? pr * a.drop_inv : 0.f;
+          ds[r] = pr * ((keep ? dpacc[r] * a.drop_inv : 0.f) + nd[r]);
+        } else {
+          p[r] = pr;
+          ds[r] = pr * dpacc[r];
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -1170,28 +1226,38 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_k(FArgs a) {
   }
 }
 
-template <int DP>
-int flash_fwd_launch(const FArgs &a, hipStream_t s) {
+template <int DP, bool DROP>
+int flash_fwd_launch_t(const FArgs &a, hipStream_t s) {
   size_t lds = 64 * AT<DP>::RSTR + 64 * AT<DP>::TSTR;
   if (lds < (size_t)128 * AT<DP>::RSTR) lds = (size_t)128 * AT<DP>::RSTR;   // the epilogue stages O through LDS
   dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
-  hipLaunchKernelGGL(flash_fwd_k<DP>, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((flash_fwd_k<DP, DROP>), grid, dim3(256), lds, s, a);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <int DP>
+int flash_fwd_launch(const FArgs &a, hipStream_t s) {
+  return a.drop_thresh ? flash_fwd_launch_t<DP, true>(a, s) : flash_fwd_launch_t<DP, false>(a, s);
+}
+
+template <int DP, bool DROP>
+int flash2_fwd_launch_t(const FArgs &a, hipStream_t s) {
+  constexpr int lds = 4 * Lay<DP>::TILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)flash2_fwd_k<DP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
+  hipLaunchKernelGGL((flash2_fwd_k<DP, DROP>), grid, dim3(256), lds, s, a);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }
 
 template <int DP>
 int flash2_fwd_launch(const FArgs &a, hipStream_t s) {
-  constexpr int lds = 4 * Lay<DP>::TILE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)flash2_fwd_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
-  hipLaunchKernelGGL(flash2_fwd_k<DP>, grid, dim3(256), lds, s, a);
-  LDM_CHECK_LAUNCH();
-  return LDM_OK;
+  return a.drop_thresh ? flash2_fwd_launch_t<DP, true>(a, s) : flash2_fwd_launch_t<DP, false>(a, s);
 }
 
 // LDM_ATTN_DMA=0 pins the register-staged kernels (A/B measurements)
@@ -1204,31 +1270,41 @@ bool attn_dma_enabled() {
   return v == 1;
 }
 
-template <int DP>
-int flash2_bwd_launch(const FArgs &a, hipStream_t s) {
+template <int DP, bool DROP>
+int flash2_bwd_launch_t(const FArgs &a, hipStream_t s) {
   constexpr int lds_dq = 4 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)flash2_bwd_dq_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
-    (void)hipFuncSetAttribute((const void *)flash2_bwd_dkv_k<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
+    (void)hipFuncSetAttribute((const void *)flash2_bwd_dq_k<DP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute((const void *)flash2_bwd_dkv_k<DP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
     attr_set = true;
   }
   dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
-  hipLaunchKernelGGL(flash2_bwd_dq_k<DP>, grid, dim3(256), lds_dq, s, a);
+  hipLaunchKernelGGL((flash2_bwd_dq_k<DP, DROP>), grid, dim3(256), lds_dq, s, a);
   LDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(flash2_bwd_dkv_k<DP>, grid, dim3(256), lds_dkv, s, a);
+  hipLaunchKernelGGL((flash2_bwd_dkv_k<DP, DROP>), grid, dim3(256), lds_dkv, s, a);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+template <int DP>
+int flash2_bwd_launch(const FArgs &a, hipStream_t s) {
+  return a.drop_thresh ? flash2_bwd_launch_t<DP, true>(a, s) : flash2_bwd_launch_t<DP, false>(a, s);
+}
+
+template <int DP, bool DROP>
+int flash_bwd_launch_t(const FArgs &a, hipStream_t s) {
+  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
+  hipLaunchKernelGGL((flash_bwd_dq_k<DP, DROP>), grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
+  LDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL((flash_bwd_dkv_k<DP, DROP>), grid, dim3(256), (size_t)128 * AT<DP>::RSTR + 512, s, a);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }
 
 template <int DP>
 int flash_bwd_launch(const FArgs &a, hipStream_t s) {
-  dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
-  hipLaunchKernelGGL(flash_bwd_dq_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR, s, a);
-  LDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(flash_bwd_dkv_k<DP>, grid, dim3(256), (size_t)128 * AT<DP>::RSTR + 512, s, a);
-  LDM_CHECK_LAUNCH();
-  return LDM_OK;
+  return a.drop_thresh ? flash_bwd_launch_t<DP, true>(a, s) : flash_bwd_launch_t<DP, false>(a, s);
 }
 
 int check(const FArgs &a) {
@@ -1242,8 +1318,11 @@ int check(const FArgs &a) {
 }  // namespace
 
 int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
-                       int64_t hd, bf16_t *o, int64_t ld_o, float *lse, hipStream_t s) {
+                       int64_t hd, bf16_t *o, int64_t ld_o, float *lse, unsigned drop_thresh, uint64_t seed,
+                       hipStream_t s) {
   FArgs a{};
+  a.drop_thresh = drop_thresh; a.drop_inv = (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh));
+  a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
   a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
   a.o = o; a.ld_o = ld_o; a.lse = lse;
 #ifdef LDM_ATTN_TIMING
@@ -1265,8 +1344,10 @@ int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
 int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
                        int64_t hd, const bf16_t *o, const bf16_t *dout, int64_t ld_o, const float *lse,
                        bf16_t *dqkv, float *delta, const float *rope_cos, const float *rope_sin, float rope_scale,
-                       hipStream_t s) {
+                       unsigned drop_thresh, uint64_t seed, hipStream_t s) {
   FArgs a{};
+  a.drop_thresh = drop_thresh; a.drop_inv = (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh));
+  a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
   if (rope_cos) {   // fused un-rotation: head dim must fill its template and the tables must be 16-byte aligned
     if (!rope_sin || !(hd == 32 || hd == 64 || hd == 96 || hd == 128)) return LDM_E_SHAPE;
     if (!aligned_to(rope_cos, 16) || !aligned_to(rope_sin, 16)) return LDM_E_ALIGN;

@@ -13,6 +13,24 @@
 
 typedef unsigned short bf16_t;  // raw bfloat16 storage
 
+// Attention-probability dropout (src/transformer.py:278 of the reference applies nn.Dropout to the
+// softmax output).  Element (batch*head, query, key) is KEPT iff a 32-bit hash of its coordinates
+// and the call's 64-bit seed is >= thresh = round(p * 2^32); kept elements are scaled by
+// 1 / (1 - thresh / 2^32).  The mask is a pure function of the coordinates, so the forward and the
+// backward kernels regenerate it in whatever layout they hold the probabilities in, and nothing is
+// stored.  oracle/dropout_oracle.py restates these three functions.
+__device__ __forceinline__ unsigned ldm_mix32(unsigned h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ unsigned ldm_drop_bh(unsigned seed_lo, unsigned bh) { return ldm_mix32(seed_lo + bh * 0x9e3779b1u); }
+__device__ __forceinline__ unsigned ldm_drop_row(unsigned bhkey, unsigned seed_hi, unsigned q) {
+  return ldm_mix32(bhkey ^ (seed_hi + q * 0x85ebca77u));
+}
+__device__ __forceinline__ bool ldm_drop_keep(unsigned rowkey, unsigned k, unsigned thresh) {
+  return ldm_mix32(rowkey + k * 0xc2b2ae3du) >= thresh;
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned)v) << 16);
 }

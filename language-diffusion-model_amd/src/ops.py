@@ -550,10 +550,13 @@ def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None)
 
 # ----------------------------------------------------------------------------
 class _RopeAttention(torch.autograd.Function):
-    """RoPE(q,k), q/sqrt(hd), softmax(q k^T + key mask) v on a fused qkv activation."""
+    """RoPE(q,k), q/sqrt(hd), dropout(softmax(q k^T + key mask)) v on a fused qkv activation.
+
+    ``dropout_p`` > 0 drops attention probabilities (src/transformer.py:278 of the reference) with a
+    mask the kernels regenerate from ``seed`` and the element coordinates; nothing is stored."""
 
     @staticmethod
-    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin):
+    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin, dropout_p=0.0, seed=0):
         N.require_device(qkv)
         lib = N.lib()
         dt = qkv.dtype
@@ -569,10 +572,19 @@ class _RopeAttention(torch.autograd.Function):
                                 1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
         o = torch.empty(B * S, D, dtype=dt, device=qkv.device)
         saved = torch.empty(lib.ldm_attn_saved_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
-        N.check(lib.ldm_attn_fwd(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
-                                 saved.data_ptr(), N.stream()), "ldm_attn_fwd")
+        if dropout_p > 0.0:
+            # the fp32 path materialises the probabilities: it needs room for their dropped copy
+            ws = (torch.empty(lib.ldm_attn_bwd_ws_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
+                  if dt == torch.float32 else None)
+            N.check(lib.ldm_attn_fwd_dropout(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
+                                             saved.data_ptr(), N.ptr(ws), float(dropout_p), int(seed), N.stream()),
+                    "ldm_attn_fwd_dropout")
+        else:
+            N.check(lib.ldm_attn_fwd(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
+                                     saved.data_ptr(), N.stream()), "ldm_attn_fwd")
         ctx.save_for_backward(q2, o, saved, cos, sin)
         ctx.key_valid = key_valid
+        ctx.dropout = (float(dropout_p), int(seed))
         ctx.dims = (B, S, H, hd)
         return o.view(B, S, D)
 
@@ -590,6 +602,17 @@ class _RopeAttention(torch.autograd.Function):
         g = g.contiguous()
         dqkv = torch.empty_like(q2)
         ws = torch.empty(lib.ldm_attn_bwd_ws_bytes(code, B, H, S, hd), dtype=torch.uint8, device=q2.device)
+        p_drop, seed = ctx.dropout
+        if p_drop > 0.0:
+            fused = FUSED_UNROPE and dt == torch.bfloat16 and hd in (32, 64, 96, 128)
+            N.check(lib.ldm_attn_bwd_dropout(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                             g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
+                                             cos.data_ptr() if fused else None, sin.data_ptr() if fused else None,
+                                             1.0 / math.sqrt(hd), p_drop, seed, N.stream()), "ldm_attn_bwd_dropout")
+            if not fused:
+                N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
+                                        1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
+            return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None
         # attention backward with the rotary backward fused into its stores where the kernel has it
         rc = -3
         if FUSED_UNROPE and dt == torch.bfloat16:
@@ -604,12 +627,16 @@ class _RopeAttention(torch.autograd.Function):
                     "ldm_attn_bwd")
             N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
                                     1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
-        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None
+        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None
 
 
 def rope_attention(qkv: Tensor, key_valid: Tensor | None, B: int, S: int, H: int, hd: int, cos: Tensor,
-                   sin: Tensor) -> Tensor:
-    return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin)
+                   sin: Tensor, dropout_p: float = 0.0, seed: int | None = None) -> Tensor:
+    """``dropout_p`` > 0: attention-probability dropout; ``seed`` (63 bits) defaults to a draw from
+    torch's CPU generator, so ``torch.manual_seed`` reproduces the masks."""
+    if dropout_p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin, float(dropout_p), int(seed or 0))
 
 
 # ----------------------------------------------------------------------------

@@ -187,10 +187,6 @@ class RotaryMultiheadAttention(nn.Module):
         if attn_mask is not None:
             raise NotImplementedError("additive attn_mask is never supplied by the model "
                                       "(src/transformer.py:435) and is not implemented in the HIP path")
-        if self.training and self.dropout.p > 0 and not self._warned:
-            warnings.warn("attention-probability dropout (src/transformer.py:278) is not applied by the "
-                          "fused attention kernel; the two residual dropouts are", stacklevel=2)
-            self._warned = True
         bsz, seq, _ = query.shape
         cos, sin = self.rotary_emb.half_tables(query, seq)
         key_valid = None
@@ -200,7 +196,9 @@ class RotaryMultiheadAttention(nn.Module):
             if key_valid is None:
                 key_valid = _key_valid_bytes(key_padding_mask)
         qkv = ops.packed_linear(query, self._pack("qkv"))
-        attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin)
+        # dropout on the attention probabilities (src/transformer.py:278) happens inside the kernels
+        p_drop = self.dropout.p if self.training else 0.0
+        attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin, dropout_p=p_drop)
         return ops.packed_linear(attn, self._pack("out"), residual=residual)
 
 

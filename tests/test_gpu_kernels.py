@@ -302,8 +302,9 @@ def test_colsum(dev):
 
 
 # ------------------------------------------------------------------ attention
-def _attn_ref(qkv, key_valid, B, S, H, hd):
-    """Reference arithmetic of src/transformer.py:246-285 in fp64 (RoPE + scale included)."""
+def _attn_ref(qkv, key_valid, B, S, H, hd, keep=None, keep_scale=1.0):
+    """Reference arithmetic of src/transformer.py:246-285 in fp64 (RoPE + scale included); ``keep``
+    [B,H,S,S] bool with ``keep_scale`` = 1/(1-p) is the dropout of line 278 with a given mask."""
     from oracle import step_oracle as so
     D = H * hd
     x = qkv.double().view(B, S, 3, H, hd)
@@ -317,7 +318,10 @@ def _attn_ref(qkv, key_valid, B, S, H, hd):
     s = (q / math.sqrt(hd)) @ k.transpose(-2, -1)
     if key_valid is not None:
         s = s.masked_fill(~key_valid.bool()[:, None, None, :], float("-inf"))
-    o = torch.softmax(s, -1) @ v
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = torch.where(keep, pr * keep_scale, torch.zeros_like(pr))
+    o = pr @ v
     return o.transpose(1, 2).reshape(B, S, D)
 
 
@@ -349,6 +353,55 @@ def test_attention_fwd_bwd(dev, dtype, B, S, H, hd, ragged):
     gq, gr = qkv.grad.float().view(B, S, 3, D), qr.grad.view(B, S, 3, D)
     for i, nm in enumerate("qkv"):
         assert rel_err(gq[:, :, i], gr[:, :, i]) < tol, f"d{nm}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,H,hd,ragged,p", [(3, 10, 4, 8, True, 0.25), (2, 48, 2, 96, True, 0.1), (2, 130, 2, 64, True, 0.1),
+                                               (1, 256, 2, 128, False, 0.3), (2, 200, 3, 32, True, 0.5),
+                                               (1, 512, 8, 96, False, 0.1), (2, 200, 2, 128, True, 0.1),
+                                               (2, 130, 3, 96, True, 0.9)])
+def test_attention_dropout_fwd_bwd(dev, dtype, B, S, H, hd, ragged, p):
+    """Dropout on the attention probabilities (src/transformer.py:278): output and gradients equal a
+    plain attention that multiplies the softmax by the SAME mask, rebuilt on the host from the seed
+    by oracle/dropout_oracle.py; the kept fraction is 1 - p.  (The reference's own masks come from
+    torch's generator: parity with them is statistical only.)"""
+    from oracle import dropout_oracle as do
+    from src import ops
+    from src.transformer import RotaryPositionEmbedding
+    torch.manual_seed(0)
+    D = H * hd
+    seed = 0x1234_5678_9ABC_DEF0 ^ (S * 7919 + hd)
+    qkv = (torch.randn(B, S, 3 * D, device=dev) * 1.5).to(dtype).requires_grad_(True)
+    key_valid = None
+    if ragged:
+        lens = torch.randint(max(2, S // 2), S + 1, (B,))
+        lens[0] = S
+        key_valid = (torch.arange(S)[None, :] < lens[:, None]).to(torch.uint8).to(dev)
+    cos, sin = RotaryPositionEmbedding(hd).half_tables(qkv, S)
+    go = torch.randn(B, S, D, device=dev).to(dtype)
+    for fused in ((True, False) if dtype == torch.bfloat16 and hd in (32, 64, 96, 128) else (True,)):
+        ops.FUSED_UNROPE = fused
+        try:
+            qkv.grad = None
+            o = ops.rope_attention(qkv * 1.0, key_valid, B, S, H, hd, cos, sin, dropout_p=p, seed=seed)
+            o.backward(go)
+        finally:
+            ops.FUSED_UNROPE = True
+        keep_np = do.keep_mask(p, seed, B * H, S, S)
+        assert abs(float(keep_np.mean()) - (1.0 - p)) < 4.0 * math.sqrt(p * (1 - p) / keep_np.size) + 1e-3
+        keep = torch.from_numpy(keep_np).to(dev).view(B, H, S, S)
+        qr = qkv.detach().clone().requires_grad_(True)
+        orf = _attn_ref(qr, key_valid, B, S, H, hd, keep=keep, keep_scale=do.scale(p))
+        orf.backward(go.double())
+        tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+        assert rel_err(o, orf) < tol, "forward"
+        gq, gr = qkv.grad.float().view(B, S, 3, D), qr.grad.view(B, S, 3, D)
+        for i, nm in enumerate("qkv"):
+            assert rel_err(gq[:, :, i], gr[:, :, i]) < tol, f"d{nm} fused={fused}"
+    # a different seed gives a different mask, the same seed the same output
+    o2 = ops.rope_attention(qkv.detach() * 1.0, key_valid, B, S, H, hd, cos, sin, dropout_p=p, seed=seed)
+    o3 = ops.rope_attention(qkv.detach() * 1.0, key_valid, B, S, H, hd, cos, sin, dropout_p=p, seed=seed + 1)
+    assert torch.equal(o2, o.detach()) and not torch.equal(o3, o2)
 
 
 @pytest.mark.parametrize("B,S,H,hd", [(2, 130, 2, 64), (1, 512, 8, 96), (2, 200, 3, 32), (1, 256, 2, 128)])

@@ -387,3 +387,43 @@ def test_weight_copies_follow_a_fused_torch_optimizer(dev):
         for wt, n in zip(pk.weights, pk.n_each):
             assert torch.equal(pk.w[off:off + n], wt.detach().to(pk.w.dtype))
             off += n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_with_dropout(dev, dtype):
+    """dropout > 0 (configs/default.yaml:13 has 0.1): attention-probability dropout runs inside the
+    attention kernels and the two residual dropouts around them; reproducible under torch.manual_seed,
+    different from the dropout-free loss, and switched off by eval()."""
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    g = load_golden("step_hd96.npz")
+    V, d, H, L, Fd = [int(x) for x in g["cfg"]]
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    att = torch.from_numpy(g["attention_mask"]).to(dev)
+    masked = torch.from_numpy(g["masked_input_ids"]).to(dev)
+    torch.manual_seed(5)
+    tr = DiffusionTransformer(DiffusionTransformerConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd,
+                                                         dropout=0.3, layer_norm_eps=1e-12)).to(dev).set_compute_dtype(dtype)
+
+    def loss_and_grads(seed):
+        tr.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        loss = tr.masked_token_loss(masked, ids, 103, att)
+        loss.backward()
+        return loss.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()}
+
+    tr.train()
+    l1, g1 = loss_and_grads(1)
+    l1b, g1b = loss_and_grads(1)
+    l2, _ = loss_and_grads(2)
+    assert math.isfinite(l1) and l1 == l1b and l1 != l2
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for n in g1:
+        assert torch.isfinite(g1[n]).all(), n
+        if not n.endswith("k_proj.bias"):          # split-K float atomics: equal up to summation order
+            assert rel_err(g1[n], g1b[n]) < tol, n
+    assert float(g1["layers.0.self_attn.v_proj.weight"].abs().max()) > 0.0
+    tr.eval()
+    with torch.no_grad():
+        e1 = tr.masked_token_loss(masked, ids, 103, att).item()
+        e2 = tr.masked_token_loss(masked, ids, 103, att).item()
+    assert e1 == e2 and e1 != l1

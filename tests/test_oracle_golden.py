@@ -130,3 +130,21 @@ def test_synth_token_oracle_contract():
     assert (ids[mask == 0] == 0).all()
     full, fmask = synth_tokens(2, 9, 1000, 30522, 101, 102, 0, 9, seed=11, offset=0)
     assert fmask.all() and (full[:, -1] == 102).all()
+
+
+def test_dropout_mask_oracle_properties():
+    """The dropout-mask restatement: deterministic in (seed, coordinates), keep rate 1 - p, rows and
+    heads decorrelated, threshold / scale arithmetic of the C side."""
+    from oracle import dropout_oracle as do
+    assert do.threshold(0.0) == 0 and do.threshold(0.5) == 2 ** 31 and do.threshold(0.99999999) <= 2 ** 32 - 1
+    assert abs(do.scale(0.1) - 1.0 / (1.0 - do.threshold(0.1) / 2.0 ** 32)) < 1e-6
+    m = do.keep_mask(0.1, 12345, 6, 64, 128)
+    assert m.shape == (6, 64, 128) and m.dtype == bool
+    assert np.array_equal(m, do.keep_mask(0.1, 12345, 6, 64, 128))
+    assert not np.array_equal(m, do.keep_mask(0.1, 12346, 6, 64, 128))
+    assert abs(m.mean() - 0.9) < 0.01
+    # no two (batch*head, query) rows share a mask, and the per-key keep rate is flat
+    rows = {r.tobytes() for r in m.reshape(-1, 128)}
+    assert len(rows) == 6 * 64
+    assert np.all(np.abs(m.reshape(-1, 128).mean(0) - 0.9) < 0.08)
+    assert do.keep_mask(0.0, 1, 2, 8, 8).all()
