@@ -203,6 +203,15 @@ int ldm_attn_bwd_dropout(int dtype, const void *qkv, int64_t ld_qkv, const uint8
                          const float *cos_t, const float *sin_t, float q_scale, float p, uint64_t seed,
                          void *stream);
 
+/* ---------------------------------------------------------------- residual dropout
+ * out = res + keep * y / (1 - p): the `src + self.dropout(...)` of the encoder layer
+ * (src/transformer.py:352,361) in one pass; res == NULL gives plain dropout, which is also the
+ * backward (gy = keep * g / (1 - p) with the forward's p and seed).  y/res/out: [rows, d] contiguous.
+ * keep(row, col) is the coordinate hash of the attention dropout (csrc/common.h) with the batch*head
+ * slot fixed at 0xffffffff: regenerated, never stored.  p in [0, 1). */
+int ldm_dropout_add(const void *y, const void *res, void *out, int64_t rows, int64_t d, int dtype,
+                    float p, uint64_t seed, void *stream);
+
 /* ---------------------------------------------------------------- K4: masked cross-entropy
  * masked_cross_entropy_loss / variational_lower_bound_loss (src/loss.py:8-65).
  * A row r of logits [T, V] (ld elements per row) takes part when

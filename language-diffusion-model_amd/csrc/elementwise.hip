@@ -642,6 +642,67 @@ inline unsigned stream_grid(int64_t work_items, int per_block) {
   return (unsigned)b;
 }
 
+// ------------------------------------------------------------------ residual dropout
+// out = res + keep * y / (1 - p)   (src/transformer.py:352,361: src + self.dropout(sublayer(src)))
+// and its backward gy = keep * g / (1 - p).  keep(row, col) is the hash of common.h with the
+// batch*head slot set to 0xffffffff, regenerated by the backward: no mask is stored.
+constexpr unsigned DROP_STREAM = 0xffffffffu;
+
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void dropout8_k(const T *__restrict__ y, const T *__restrict__ res,
+                                                  T *__restrict__ out, int64_t rows, int d, unsigned thresh,
+                                                  float inv, unsigned seed_lo, unsigned seed_hi) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = d >> 3;
+  const unsigned streamkey = ldm_drop_bh(seed_lo, DROP_STREAM);
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const unsigned rowkey = ldm_drop_row(streamkey, seed_hi, (unsigned)r);
+    for (int v = lane; v < nvec; v += 64) {
+      Raw8<T> a, b;
+      a.load(y + r * d + v * 8);
+      if (ADD) b.load(res + r * d + v * 8);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float kept = ldm_drop_keep(rowkey, (unsigned)(v * 8 + j), thresh) ? a.get(j) * inv : 0.f;
+        o[j] = ADD ? b.get(j) + kept : kept;
+      }
+      Raw8<T>::store(out + r * d + v * 8, o);
+    }
+  }
+}
+
+// any width / alignment
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void dropout_scalar_k(const T *y, const T *res, T *out, int64_t rows, int64_t d,
+                                                        unsigned thresh, float inv, unsigned seed_lo,
+                                                        unsigned seed_hi) {
+  const unsigned streamkey = ldm_drop_bh(seed_lo, DROP_STREAM);
+  const int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / d;
+    const unsigned rowkey = ldm_drop_row(streamkey, seed_hi, (unsigned)r);
+    const float kept = ldm_drop_keep(rowkey, (unsigned)(i - r * d), thresh) ? Elt<T>::ld(y + i) * inv : 0.f;
+    Elt<T>::st(out + i, ADD ? Elt<T>::ld(res + i) + kept : kept);
+  }
+}
+
+template <typename T, bool ADD>
+int dropout_launch(const void *y, const void *res, void *out, int64_t rows, int64_t d, unsigned thresh, float inv,
+                   uint64_t seed, hipStream_t s) {
+  const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
+  if (d % 8 == 0 && d < (1 << 28) && aligned_to(y, 16) && aligned_to(out, 16) && (!ADD || aligned_to(res, 16)))
+    hipLaunchKernelGGL((dropout8_k<T, ADD>), dim3(stream_grid(rows, 4)), dim3(256), 0, s, (const T *)y, (const T *)res,
+                       (T *)out, rows, (int)d, thresh, inv, lo, hi);
+  else
+    hipLaunchKernelGGL((dropout_scalar_k<T, ADD>), dim3(stream_grid(rows * d, 256)), dim3(256), 0, s, (const T *)y,
+                       (const T *)res, (T *)out, rows, d, thresh, inv, lo, hi);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
 inline int rms_nv(int64_t d) {
   const int64_t need = ceil_div(d / 4, 64);
   int nv = 1;
@@ -984,4 +1045,23 @@ extern "C" int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void
                      (bf16_t *)dst, n / 4, n);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
+}
+
+extern "C" int ldm_dropout_add(const void *y, const void *res, void *out, int64_t rows, int64_t d, int dtype, float p,
+                               uint64_t seed, void *stream) {
+  if (rows < 0 || d <= 0 || !(p >= 0.0f) || !(p < 1.0f)) return LDM_E_BADARG;
+  if (rows == 0) return LDM_OK;
+  if (!y || !out) return LDM_E_BADARG;
+  if (rows > 0xffffffffll || d > 0xffffffffll) return LDM_E_SHAPE;   // 32-bit coordinates in the mask hash
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  const float inv = (float)(4294967296.0 / (4294967296.0 - (double)thresh));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_F32)
+    return res ? dropout_launch<float, true>(y, res, out, rows, d, thresh, inv, seed, s)
+               : dropout_launch<float, false>(y, res, out, rows, d, thresh, inv, seed, s);
+  if (dtype == LDM_BF16)
+    return res ? dropout_launch<bf16_t, true>(y, res, out, rows, d, thresh, inv, seed, s)
+               : dropout_launch<bf16_t, false>(y, res, out, rows, d, thresh, inv, seed, s);
+  return LDM_E_DTYPE;
 }

@@ -102,7 +102,7 @@ extern "C" int ldm_gemm_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *
   return ldm_gemm_mfma256_bf16_swiglu_bwd(T, F, K, dy, ld_dy, W, ldw, ag, ld_ag, dag, ld_dag, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 10; }
+extern "C" int ldm_abi_version(void) { return 11; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

@@ -549,6 +549,46 @@ def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None)
 
 
 # ----------------------------------------------------------------------------
+class _DropoutAdd(torch.autograd.Function):
+    """res + dropout(y) in one pass; the mask is a hash of (seed, row, column), regenerated in
+    backward (src/transformer.py:352,361 of the reference: ``src + self.dropout(...)``)."""
+
+    @staticmethod
+    def forward(ctx, y, res, p, seed):
+        N.require_device(y, res)
+        yc = y.contiguous()
+        rc = res.contiguous()
+        if rc.dtype != yc.dtype:
+            rc = rc.to(yc.dtype)
+        d = yc.shape[-1]
+        out = torch.empty_like(yc)
+        N.check(N.lib().ldm_dropout_add(yc.data_ptr(), rc.data_ptr(), out.data_ptr(), yc.numel() // d, d,
+                                        N.dtype_code(yc.dtype), float(p), int(seed), N.stream()), "ldm_dropout_add")
+        ctx.args = (float(p), int(seed), res.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, res_dtype = ctx.args
+        gc_ = g.contiguous()
+        d = gc_.shape[-1]
+        gy = torch.empty_like(gc_)
+        N.check(N.lib().ldm_dropout_add(gc_.data_ptr(), None, gy.data_ptr(), gc_.numel() // d, d,
+                                        N.dtype_code(gc_.dtype), p, seed, N.stream()), "ldm_dropout_add(backward)")
+        return gy, (g if g.dtype == res_dtype else g.to(res_dtype)), None, None
+
+
+def dropout_add(y: Tensor, residual: Tensor, p: float, seed: int | None = None) -> Tensor:
+    """``residual + dropout(y, p)`` (training semantics); ``seed`` defaults to a draw from torch's
+    CPU generator."""
+    if p <= 0.0:
+        return residual + y
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _DropoutAdd.apply(y, residual, float(p), int(seed))
+
+
+# ----------------------------------------------------------------------------
 class _RopeAttention(torch.autograd.Function):
     """RoPE(q,k), q/sqrt(hd), dropout(softmax(q k^T + key mask)) v on a fused qkv activation.
 

@@ -221,14 +221,15 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src: Tensor, src_mask: Tensor | None = None,
                 src_key_padding_mask: Tensor | None = None) -> Tensor:
-        drop = self.training and self.dropout.p > 0
-        if drop:
-            src_norm = self.norm1(src)
+        if self.training and self.dropout.p > 0:
+            # the two residual dropouts (src/transformer.py:352,361), each fused with its addition
+            p = self.dropout.p
+            src_norm, src = self.norm1.with_residual(src)
             attn_output = self.self_attn(src_norm, src_norm, src_norm, attn_mask=src_mask,
                                          key_padding_mask=src_key_padding_mask)
-            src = src + self.dropout(attn_output)
-            src_norm = self.norm2(src)
-            return src + self.dropout(self.swiglu(src_norm))
+            src = ops.dropout_add(attn_output, src, p)
+            src_norm, src = self.norm2.with_residual(src)
+            return ops.dropout_add(self.swiglu(src_norm), src, p)
         # residual add fused into the projection epilogue (forward) and into the norm's
         # backward kernel (gradient of the residual stream)
         src_norm, src = self.norm1.with_residual(src)

@@ -36,11 +36,16 @@ def scale(p: float) -> float:
     return float(np.float32(4294967296.0 / (4294967296.0 - threshold(p))))
 
 
-def keep_mask(p: float, seed: int, n_bh: int, seq_q: int, seq_k: int) -> np.ndarray:
+def keep_mask_rows(p: float, seed: int, rows: int, cols: int) -> np.ndarray:
+    """bool [rows, cols]: the residual-dropout mask of ldm_dropout_add (batch*head slot 0xffffffff)."""
+    return keep_mask(p, seed, 1, rows, cols, bh0=0xFFFFFFFF)[0]
+
+
+def keep_mask(p: float, seed: int, n_bh: int, seq_q: int, seq_k: int, bh0: int = 0) -> np.ndarray:
     """bool [n_bh, seq_q, seq_k]: True where the probability of (batch*head, query, key) is kept."""
     thr = np.uint64(threshold(p))
     lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    bh = np.arange(n_bh, dtype=np.uint64)[:, None, None]
+    bh = (np.arange(n_bh, dtype=np.uint64) + np.uint64(bh0))[:, None, None]
     q = np.arange(seq_q, dtype=np.uint64)[None, :, None]
     k = np.arange(seq_k, dtype=np.uint64)[None, None, :]
     bhkey = mix32((lo + bh * np.uint64(0x9E3779B1)) & M32)

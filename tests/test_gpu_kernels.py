@@ -404,6 +404,36 @@ def test_attention_dropout_fwd_bwd(dev, dtype, B, S, H, hd, ragged, p):
     assert torch.equal(o2, o.detach()) and not torch.equal(o3, o2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d,p", [(7, 768, 0.1), (1000, 32, 0.5), (33, 13, 0.3), (4096, 2048, 0.1), (5, 8, 0.0)])
+def test_dropout_add(dev, dtype, rows, d, p):
+    """res + keep*y/(1-p) and its backward against the same mask rebuilt by oracle/dropout_oracle.py
+    (src/transformer.py:352,361: src + self.dropout(...)); keep rate 1 - p."""
+    from oracle import dropout_oracle as do
+    from src import ops
+    torch.manual_seed(rows)
+    seed = 0x0BAD_5EED_0000_0000 + rows * d
+    y = torch.randn(rows, d, device=dev).to(dtype).requires_grad_(True)
+    res = torch.randn(rows, d, device=dev).to(dtype).requires_grad_(True)
+    g = torch.randn(rows, d, device=dev).to(dtype)
+    if p == 0.0:
+        out = ops.dropout_add(y, res, p)
+        assert torch.equal(out, res + y)
+        return
+    out = ops._DropoutAdd.apply(y, res, p, seed)
+    out.backward(g)
+    keep_np = do.keep_mask_rows(p, seed, rows, d)
+    assert abs(float(keep_np.mean()) - (1.0 - p)) < 4.0 * math.sqrt(p * (1 - p) / keep_np.size) + 1e-3
+    keep = torch.from_numpy(keep_np).to(dev)
+    sc = do.scale(p)
+    want = res.detach().double() + torch.where(keep, y.detach().double() * sc, torch.zeros_like(y, dtype=torch.float64))
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert rel_err(out, want) < tol
+    assert rel_err(y.grad, torch.where(keep, g.double() * sc, torch.zeros_like(g, dtype=torch.float64))) < tol
+    assert torch.equal(res.grad, g)
+    assert float((out.detach()[~keep] - res.detach()[~keep]).abs().max()) == 0.0     # dropped: exactly the residual
+
+
 @pytest.mark.parametrize("B,S,H,hd", [(2, 130, 2, 64), (1, 512, 8, 96), (2, 200, 3, 32), (1, 256, 2, 128)])
 def test_attention_bwd_fused_unrope_matches_two_pass(dev, B, S, H, hd):
     """The rotary backward fused into the attention-backward stores gives what the separate
