@@ -22,7 +22,6 @@ autocast).  Parameters are always fp32 masters.
 from __future__ import annotations
 
 import os
-import warnings
 from dataclasses import dataclass
 
 import torch
@@ -165,7 +164,6 @@ class RotaryMultiheadAttention(nn.Module):
         self.rotary_emb = RotaryPositionEmbedding(self.head_dim)
         self.compute_dtype = _default_dtype()
         self._packs: dict = {}
-        self._warned = False
 
     def _pack(self, which: str) -> ops.PackedWeights:
         key = (which, self.compute_dtype)
