@@ -404,6 +404,24 @@ def test_attention_dropout_fwd_bwd(dev, dtype, B, S, H, hd, ragged, p):
     assert torch.equal(o2, o.detach()) and not torch.equal(o3, o2)
 
 
+def test_attention_dropout_is_unbiased(dev):
+    """nn.Dropout semantics (src/transformer.py:278): kept probabilities are scaled by 1/(1-p), so the
+    mean output over many masks tends to the dropout-free output."""
+    from src import ops
+    from src.transformer import RotaryPositionEmbedding
+    torch.manual_seed(0)
+    B, S, H, hd, p, n = 1, 128, 2, 96, 0.2, 256
+    qkv = torch.randn(B, S, 3 * H * hd, device=dev)
+    cos, sin = RotaryPositionEmbedding(hd).half_tables(qkv, S)
+    base = ops.rope_attention(qkv * 1.0, None, B, S, H, hd, cos, sin)
+    acc = torch.zeros_like(base)
+    for i in range(n):
+        acc += ops.rope_attention(qkv * 1.0, None, B, S, H, hd, cos, sin, dropout_p=p, seed=1000 + i)
+    one = ops.rope_attention(qkv * 1.0, None, B, S, H, hd, cos, sin, dropout_p=p, seed=1000)
+    err_one, err_mean = rel_err(one, base), rel_err(acc / n, base)
+    assert err_one > 0.1 and err_mean < 2.0 * err_one / math.sqrt(n), (err_one, err_mean)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,d,p", [(7, 768, 0.1), (1000, 32, 0.5), (33, 13, 0.3), (4096, 2048, 0.1), (5, 8, 0.0)])
 def test_dropout_add(dev, dtype, rows, d, p):

@@ -427,3 +427,49 @@ def test_training_with_dropout(dev, dtype):
         e1 = tr.masked_token_loss(masked, ids, 103, att).item()
         e2 = tr.masked_token_loss(masked, ids, 103, att).item()
     assert e1 == e2 and e1 != l1
+
+
+def test_long_sequence_wide_model_properties(dev):
+    """One layer of the ~1B configuration (d=2048, 16 heads of 128, ff=5632, V=32000) at S=4096, the
+    largest sequence length of the benchmark configurations, ragged: the trainer-step loss (LM head on
+    the rows the loss reads) equals model() + variational_lower_bound_loss(), gradients agree, loss
+    is near ln(V) at random init, padded positions get no embedding gradient."""
+    import types
+    from src.loss import variational_lower_bound_loss
+    from src.masking_strategy import create_masking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    torch.manual_seed(3)
+    V, S, B = 32000, 4096, 2
+    cfg = DiffusionTransformerConfig(vocab_size=V, d_model=2048, nhead=16, num_layers=1, dim_feedforward=5632,
+                                     dropout=0.0, layer_norm_eps=1e-12, max_position_embeddings=S)
+    tr = DiffusionTransformer(cfg).to(dev).set_compute_dtype(torch.bfloat16)
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None).to(dev)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(1000, V, (B, S), generator=g)
+    ids[:, 0] = 101
+    lens = torch.tensor([S, 3001])
+    att = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ids = torch.where(att == 1, ids, torch.zeros_like(ids))
+    ids, att = ids.to(dev), att.to(dev)
+    t = torch.tensor([0.3], device=dev)
+    out = {}
+    for fused in (True, False):
+        tr.zero_grad(set_to_none=True)
+        torch.manual_seed(7)
+        if fused:
+            loss = model.training_loss(ids, att, t=t)
+        else:
+            logits, masked, _ = model(ids, att, t=t)
+            loss = variational_lower_bound_loss(logits, ids, masked, 103, att)
+        loss.backward()
+        out[fused] = (loss.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()})
+    (lf, gf), (ld, gd) = out[True], out[False]
+    assert math.isfinite(lf) and abs(lf - math.log(V)) < 1.5
+    assert abs(lf - ld) <= 1e-5 * abs(ld)
+    for n in gd:
+        if n.endswith("k_proj.bias"):
+            continue
+        assert rel_err(gf[n], gd[n]) < 5e-3, n
+    assert float(gf["embedding.weight"][0].abs().max()) == 0.0      # pad id: masked out of loss and never a key
