@@ -147,6 +147,14 @@ int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int transB, int64_
  * (the caller then makes the two calls). */
 int ldm_gemm_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
                         int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag, void *stream);
+/* SwiGLU forward inside the gate/up projection (src/transformer.py:91-95: w1(x) * silu(w2(x))):
+ * ag[T, 2F] = x W12^T + bias (columns [a | g], what ldm_gemm with the packed weight gives) AND
+ * h[T, F] = a * silu(g) from ONE GEMM, so the activation is never a separate pass.  W12 = [w1; w2],
+ * [2F, K] with K contiguous; bias fp32 [2F] or NULL.  BF16; T a multiple of 256, F of 128, K of 32,
+ * row strides multiples of 8; otherwise LDM_E_SHAPE / LDM_E_ALIGN (use ldm_gemm + ldm_swiglu_fwd). */
+int ldm_gemm_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W12,
+                        int64_t ldw, const float *bias, void *ag, int64_t ld_ag, void *h, int64_t ld_h,
+                        void *stream);
 
 /* Column sums (bias gradients): out[n] = sum_m X[m,n]; out fp32 [N], overwritten.
  * ws must hold ldm_colsum_ws_floats(M,N) floats. */

@@ -39,3 +39,7 @@ int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N,
 int ldm_gemm_mfma256_bf16_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
                                      int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag,
                                      hipStream_t s);
+// SwiGLU forward fused into the gate/up projection: [a | g] and h = a * silu(g) from one GEMM
+int ldm_gemm_mfma256_bf16_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W12,
+                                     int64_t ldw, const float *bias, void *ag, int64_t ld_ag, void *h, int64_t ld_h,
+                                     hipStream_t s);

@@ -102,7 +102,14 @@ extern "C" int ldm_gemm_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *
   return ldm_gemm_mfma256_bf16_swiglu_bwd(T, F, K, dy, ld_dy, W, ldw, ag, ld_ag, dag, ld_dag, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 11; }
+extern "C" int ldm_gemm_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W12,
+                                   int64_t ldw, const float *bias, void *ag, int64_t ld_ag, void *h, int64_t ld_h,
+                                   void *stream) {
+  if (T <= 0 || F <= 0 || K <= 0 || !x || !W12 || !ag || !h) return LDM_E_BADARG;
+  return ldm_gemm_mfma256_bf16_swiglu_fwd(T, F, K, x, ldx, W12, ldw, bias, ag, ld_ag, h, ld_h, (hipStream_t)stream);
+}
+
+extern "C" int ldm_abi_version(void) { return 12; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

@@ -53,6 +53,8 @@ struct MArgs {
   const float *bias;
   const void *R; int64_t ldr;
   int64_t gate_off;   // RES 2: columns of the gate half in R and C (R = [a | g], C = [da | dg])
+                      // RES 3: rows of the gate weights in B = [w1; w2] and columns of g in C = [a | g]
+  void *C2; int64_t ldc2;   // RES 3: h = a * silu(g), [M, gate_off]
   int tiles_m, tiles_n, splits;
   // optional device-side sizes (a row count known only on the GPU): rows >= *dyn_m of A/C do
   // not exist; K is *dyn_k rounded up to 32 (the caller zero-fills the rounding rows);
@@ -80,14 +82,16 @@ __device__ __forceinline__ int swz_st(int kr) { return ((kr & 3) | (((kr >> 3) &
 // operand with ROWS rows (KC) or ROWS columns (strided).  Piece index = wave + 8*i.
 template <bool KC, int ROWS>
 __device__ __forceinline__ void stage_ptrs(const bf16_t *P, int64_t ld, int64_t row0, int64_t nrows, int wave,
-                                           int lane, const bf16_t *(&src)[ROWS / 128]) {
+                                           int lane, const bf16_t *(&src)[ROWS / 128], int64_t gate_rows = 0) {
 #pragma unroll
   for (int i = 0; i < ROWS / 128; ++i) {
     const int piece = wave + 8 * i;
     if (KC) {
       const int r = piece * 16 + (lane >> 2);
       const int lc = (lane & 3) ^ swz_kc(r);
-      int64_t gr = row0 + r;
+      // gate_rows != 0 (SwiGLU forward): tile rows come in blocks of 32, alternately from the first
+      // operand half (rows row0 + 32 j ..) and from the same rows gate_rows further down
+      int64_t gr = gate_rows ? row0 + ((r >> 6) << 5) + (r & 31) + ((r >> 5) & 1) * gate_rows : row0 + r;
       if (gr > nrows - 1) gr = nrows - 1;
       src[i] = P + gr * ld + lc * 8;
     } else {
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   int p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
   int np = base + (tid.split < rem ? 1 : 0);
   stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
-  stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * BN, g.N, wave, lane, srcB);
+  stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
+                       RES == 3 ? g.gate_off : 0);
 #pragma unroll
   for (int p = 0; p < 3; ++p)
     if (p < np) {
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     }
 
   // stores per wave in the fast-path epilogue (16 bytes per lane each)
-  constexpr int NST = MI * (sizeof(TO) == 2 ? 2 : 4) * (RES == 2 ? 2 : 1);
+  constexpr int NST = RES == 3 ? MI * 3 : MI * (sizeof(TO) == 2 ? 2 : 4) * (RES == 2 ? 2 : 1);
   static_assert(2 * P + NST <= 63, "vmcnt is a 6-bit counter");
 #ifdef LDM_GEMM_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -234,6 +239,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         if (n + j < g.N) bv[j] = g.bias[n + j];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) asm volatile("" : "+v"(bv[j]));
+    }
+
+    // RES 3: biases of this lane's accumulator columns (fragments 0-1: a, 2-3: g of the same hidden columns)
+    f4_t bag[RES == 3 ? 4 : 1];
+    if (RES == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bag[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+          const int64_t hc = (int64_t)tid.tn * (BN / 2) + wn * 32 + (i & 1) * 16 + (lane >> 4) * 4 + (i >> 1) * g.gate_off;
+          bag[i] = *reinterpret_cast<const f4_t *>(g.bias + hc);
+        }
+        asm volatile("" : "+v"(bag[i]));
+      }
     }
 
     f4_t acc[NI][MI];
@@ -363,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         rr[i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr);
     }
 
+    [[maybe_unused]] const int tid_cur_tn = tid.tn;
     w += gridDim.x;
     const bool more = w < total;
     if (more) {
@@ -370,7 +390,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
       np = base + (tid.split < rem ? 1 : 0);
       stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
-      stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * BN, g.N, wave, lane, srcB);
+      stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
+                           RES == 3 ? g.gate_off : 0);
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         if (p < np) {
@@ -392,6 +413,68 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // compiler does not order them behind the LDS-DMA prefetch just issued (it would drain it
     // with vmcnt(0): it cannot see that the staging area and the ring are disjoint), and with a
     // fixed number of unconditional 16-byte stores (NST), which the next item's waits count on.
+    // RES 3 (SwiGLU forward; all tiles full): h = a * silu(g) is formed in registers, where fragments
+    // ni and ni + 2 hold a and g of the same hidden columns; per 16-row fragment the wave stages
+    // [a(32) | g(32)] and then h(32) through its LDS area and writes three row-contiguous outputs.
+    if constexpr (RES == 3) {
+      TO *AG = (TO *)g.C, *HH = (TO *)g.C2;
+      const int cl = lane & 7, wrow = lane & 15;
+      const unsigned waddr = stage_lds + wrow * 256;
+      const int64_t hc0 = (int64_t)tid_cur_tn * (BN / 2) + wn * 32;
+      TO *crow = AG + (m0 + wm * (MI * 16) + (lane >> 3)) * g.ldc + (cl < 4 ? hc0 + cl * 8 : g.gate_off + hc0 + (cl - 4) * 8);
+      TO *hrow = HH + (m0 + wm * (MI * 16) + (lane >> 2)) * g.ldc2 + hc0 + (lane & 3) * 8;
+      const int64_t rstep = (int64_t)8 * g.ldc, hstep = (int64_t)16 * g.ldc2;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        f4_t hv[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f4_t av = acc[ni][mi] + bag[ni], gv = acc[ni + 2][mi] + bag[2 + ni];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hv[ni][j] = av[j] * gv[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-gv[j]));
+          asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + (((ni * 4 + (lane >> 4)) ^ wrow) << 4)), "v"(av) : "memory");
+          asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + ((((ni + 2) * 4 + (lane >> 4)) ^ wrow) << 4)), "v"(gv) : "memory");
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3);
+          f4_t t[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t[q]) : "v"(stage_lds + row * 256 + (((cl * 2 + q) ^ row) << 4)) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1])::"memory");
+          u4v_t pk;
+          pk[0] = pack_bf16x2(t[0][0], t[0][1]);
+          pk[1] = pack_bf16x2(t[0][2], t[0][3]);
+          pk[2] = pack_bf16x2(t[1][0], t[1][1]);
+          pk[3] = pack_bf16x2(t[1][2], t[1][3]);
+          __builtin_nontemporal_store(pk, reinterpret_cast<u4v_t *>(crow));
+          crow += rstep;
+        }
+        // the LDS unit executes a wave's accesses in order: h may overwrite the area just read
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + (((ni * 4 + (lane >> 4)) ^ wrow) << 4)), "v"(hv[ni]) : "memory");
+        {
+          const int row = lane >> 2;
+          f4_t t[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t[q]) : "v"(stage_lds + row * 256 + ((((lane & 3) * 2 + q) ^ row) << 4)) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1])::"memory");
+          u4v_t pk;
+          pk[0] = pack_bf16x2(t[0][0], t[0][1]);
+          pk[1] = pack_bf16x2(t[0][2], t[0][3]);
+          pk[2] = pack_bf16x2(t[1][0], t[1][1]);
+          pk[3] = pack_bf16x2(t[1][2], t[1][3]);
+          __builtin_nontemporal_store(pk, reinterpret_cast<u4v_t *>(hrow));
+          hrow += hstep;
+        }
+      }
+      carry_next = more;
+      if (!more) break;
+      continue;
+    }
     if (EPI == 0 && (SWI_FAST || (fast_tile && (!g.R || res_fast)))) {
       TO *C = (TO *)g.C;
       if (SWI_FAST) {
@@ -637,6 +720,7 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.gate_off = 0;
+  g.C2 = nullptr; g.ldc2 = 0;
   g.splits = 1;
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
   g.rowsum = nullptr;
@@ -697,6 +781,25 @@ int ldm_gemm_mfma256_bf16_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void
   g.tiles_m = (int)tm;
   g.tiles_n = (int)tn;
   return launch256<true, false, 256, bf16_t, 0, 2>(g, s);
+}
+
+// SwiGLU forward inside the gate/up projection: ag = x W12^T + b12 ([a | g], 2F columns) AND
+// h = a * silu(g) ([T, F]) from one GEMM.  W12 = [w1; w2] ([2F, K], K contiguous), bias fp32 [2F] or null.
+int ldm_gemm_mfma256_bf16_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W12,
+                                     int64_t ldw, const float *bias, void *ag, int64_t ld_ag, void *h, int64_t ld_h,
+                                     hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, 0, 1, T, 2 * F, K, 1.0f, x, ldx, W12, ldw, ag, ld_ag, bias, nullptr, 0);
+  if (rc) return rc;
+  if (T < 256 || T % 256 || F < 128 || F % 128) return LDM_E_SHAPE;
+  if (ld_ag % 8 || ld_h % 8 || ld_ag < 2 * F || ld_h < F || !aligned_to(h, 16)) return LDM_E_ALIGN;
+  const int64_t tm = T / 256, tn = F / 128;
+  if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
+  g.gate_off = F;
+  g.C2 = h; g.ldc2 = ld_h;
+  g.tiles_m = (int)tm;
+  g.tiles_n = (int)tn;
+  return launch256<true, true, 256, bf16_t, 0, 3>(g, s);
 }
 
 // Forms with device-side sizes (see MArgs): used for the LM-head backward over the compacted

@@ -185,8 +185,22 @@ class _PackedLinear(torch.autograd.Function):
             res = _rows2d(residual)
             if res.dtype != dt:
                 res = res.to(dt)
-        _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
-              res=res, ldr=res.stride(0) if res is not None else 0, tag=pack.name + ".fwd")
+        rc = -3
+        if (FUSED_SWIGLU_UP and getattr(pack, "swiglu_in", False) and res is None and dt == torch.bfloat16
+                and pack.n_pad == pack.n and len(pack.n_each) == 2 and pack.n_each[0] == pack.n_each[1]):
+            # gate/up projection of a SwiGLU: the activation h = a * silu(g) comes out of the same GEMM and is
+            # handed to swiglu_down (the call that follows) through _SWIGLU_H, keyed by this output
+            F = pack.n // 2
+            h = torch.empty(T, F, dtype=dt, device=x2.device)
+            rc = N.lib().ldm_gemm_swiglu_fwd(T, F, k, x2.data_ptr(), x2.stride(0), w.data_ptr(), k, N.ptr(b),
+                                             y.data_ptr(), pack.n_pad, h.data_ptr(), F, N.stream())
+            if rc not in (-2, -3):
+                N.check(rc, "ldm_gemm_swiglu_fwd")
+                _SWIGLU_H.clear()
+                _SWIGLU_H[y.data_ptr()] = (y, h)
+        if rc in (-2, -3):
+            _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
+                  res=res, ldr=res.stride(0) if res is not None else 0, tag=pack.name + ".fwd")
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.save_for_backward(x2, w)
@@ -456,6 +470,9 @@ def swiglu_act(ag: Tensor) -> Tensor:
 
 
 FUSED_SWIGLU_DOWN = os.environ.get("LDM_FUSED_SWIGLU", "1") != "0"   # SwiGLU backward inside the w3 input-gradient GEMM
+# SwiGLU forward inside the gate/up projection GEMM (LDM_FUSED_SWIGLU_UP=0: separate elementwise pass)
+FUSED_SWIGLU_UP = os.environ.get("LDM_FUSED_SWIGLU_UP", "1") != "0"
+_SWIGLU_H: dict = {}   # output pointer of the gate/up projection -> (output, h); consumed by swiglu_down
 
 
 class _SwiGLUDown(torch.autograd.Function):
@@ -477,8 +494,13 @@ class _SwiGLUDown(torch.autograd.Function):
         if ag2.stride(0) != F2:
             ag2 = ag2.contiguous()
         T = ag2.shape[0]
-        h = torch.empty(T, F, dtype=dt, device=ag2.device)
-        N.check(lib.ldm_swiglu_fwd(ag2.data_ptr(), T, F, N.dtype_code(dt), h.data_ptr(), N.stream()), "ldm_swiglu_fwd")
+        entry = _SWIGLU_H.pop(ag2.data_ptr(), None)
+        if entry is not None and entry[1].shape == (T, F) and entry[1].dtype == dt:
+            h = entry[1]      # formed in the epilogue of the projection that produced ag
+        else:
+            h = torch.empty(T, F, dtype=dt, device=ag2.device)
+            N.check(lib.ldm_swiglu_fwd(ag2.data_ptr(), T, F, N.dtype_code(dt), h.data_ptr(), N.stream()), "ldm_swiglu_fwd")
+        _SWIGLU_H.clear()
         y = torch.empty(T, pack.n_pad, dtype=dt, device=ag2.device)
         res = None
         if residual is not None:

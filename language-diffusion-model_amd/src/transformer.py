@@ -86,6 +86,7 @@ class SwiGLU(nn.Module):
             if which == "in":
                 self._packs[key] = ops.PackedWeights([self.w1.weight, self.w2.weight],
                                                      [self.w1.bias, self.w2.bias], self.compute_dtype, "w12")
+                self._packs[key].swiglu_in = True   # its GEMM may also emit a * silu(g)
             else:
                 self._packs[key] = ops.PackedWeights([self.w3.weight], [self.w3.bias], self.compute_dtype, "w3")
         return self._packs[key]

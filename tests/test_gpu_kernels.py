@@ -652,3 +652,59 @@ def test_gemm_swiglu_bwd_epilogue(dev, T, F, K):
                                    2 * F, N.stream()) == -3
     assert lib.ldm_gemm_swiglu_bwd(T, F - 128, K, dy.data_ptr(), K, w.data_ptr(), F, ag.data_ptr(), 2 * F,
                                    dag.data_ptr(), 2 * F, N.stream()) == -3
+
+
+@pytest.mark.parametrize("T,F,K,bias", [(256, 128, 64, True), (512, 1024, 768, True), (1024, 5632, 2048, False),
+                                        (768, 384, 96, True)])
+def test_gemm_swiglu_fwd_epilogue(dev, T, F, K, bias):
+    """ldm_gemm_swiglu_fwd: [a | g] = x W12^T + b and h = a * silu(g) (src/transformer.py:91-95) from one
+    GEMM, against fp64; shapes it does not take are declined, not mis-computed."""
+    from src import _native as Nn
+    torch.manual_seed(T + F)
+    x = torch.randn(T, K, device=dev).bfloat16()
+    W = (torch.randn(2 * F, K, device=dev) / K ** 0.5).bfloat16()
+    b = torch.randn(2 * F, device=dev) if bias else None
+    ag = torch.full((T, 2 * F), float("nan"), device=dev, dtype=torch.bfloat16)
+    h = torch.full((T, F), float("nan"), device=dev, dtype=torch.bfloat16)
+    Nn.check(Nn.lib().ldm_gemm_swiglu_fwd(T, F, K, x.data_ptr(), K, W.data_ptr(), K, Nn.ptr(b), ag.data_ptr(), 2 * F,
+                                          h.data_ptr(), F, Nn.stream()), "ldm_gemm_swiglu_fwd")
+    ref = x.double() @ W.double().t() + (b.double() if bias else 0)
+    a, g = ref[:, :F], ref[:, F:]
+    assert rel_err(ag, ref) < 4e-3
+    assert rel_err(h, a * g * torch.sigmoid(g)) < 4e-3
+    # h is what the separate activation kernel makes of the stored (bf16-rounded) [a | g], up to one rounding
+    h2 = torch.empty_like(h)
+    Nn.check(Nn.lib().ldm_swiglu_fwd(ag.data_ptr(), T, F, 1, h2.data_ptr(), Nn.stream()), "ldm_swiglu_fwd")
+    assert rel_err(h, h2) < 6e-3
+    assert Nn.lib().ldm_gemm_swiglu_fwd(T - 8, F, K, x.data_ptr(), K, W.data_ptr(), K, Nn.ptr(b), ag.data_ptr(), 2 * F,
+                                        h.data_ptr(), F, Nn.stream()) == -3
+    assert Nn.lib().ldm_gemm_swiglu_fwd(T, F - 64, K, x.data_ptr(), K, W.data_ptr(), K, Nn.ptr(b), ag.data_ptr(), 2 * F,
+                                        h.data_ptr(), F, Nn.stream()) == -3
+
+
+def test_swiglu_module_fused_up_projection_matches_two_pass(dev):
+    """SwiGLU.forward with the activation formed inside the gate/up GEMM and with the separate
+    activation pass: same output and parameter gradients up to bf16 rounding of h."""
+    from src import ops
+    from src.transformer import SwiGLU
+    torch.manual_seed(0)
+    m = SwiGLU(768, 1024, 768).to(dev)
+    m.compute_dtype = torch.bfloat16
+    x = torch.randn(2, 512, 768, device=dev).bfloat16()
+    go = torch.randn(2, 512, 768, device=dev).bfloat16()
+    out = {}
+    for fused in (True, False):
+        ops.FUSED_SWIGLU_UP = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_(True)
+            y = m(xx)
+            y.backward(go)
+        finally:
+            ops.FUSED_SWIGLU_UP = True
+        out[fused] = (y.detach().float(), xx.grad.float(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert not ops._SWIGLU_H
+    assert rel_err(out[True][0], out[False][0]) < 6e-3
+    assert rel_err(out[True][1], out[False][1]) < 6e-3
+    for n in out[True][2]:
+        assert rel_err(out[True][2][n], out[False][2][n]) < 6e-3, n
