@@ -467,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           pk[1] = pack_bf16x2(t[0][2], t[0][3]);
           pk[2] = pack_bf16x2(t[1][0], t[1][1]);
           pk[3] = pack_bf16x2(t[1][2], t[1][3]);
-          __builtin_nontemporal_store(pk, reinterpret_cast<u4v_t *>(hrow));
+          *reinterpret_cast<u4v_t *>(hrow) = pk;   // plain store: the down projection reads h next (-0.7 ms/step against non-temporal)
           hrow += hstep;
         }
       }
