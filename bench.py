@@ -1,6 +1,7 @@
 """Masked-diffusion training-step benchmark (one process per GPU).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3          # starts its 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,8 +10,14 @@ zero_grad -> forward masking -> transformer forward -> masked CE -> backward (wi
 RCCL gradient all-reduce when N > 1) -> AdamW.step -> loss.item(), on synthetic tokens that are
 resident in HBM before the timed region.  Workload: the reference's configs/default.yaml model
 (d=768, 8 heads of 96, 8 layers, ff=1024, vocab 30522) at sequence length 512, bf16 compute,
-dropout 0.0 (--dropout), per-GPU batch --batch (default 512 sequences, the YAML's own batch_size, = 262,144 tokens per
-GPU per step; weak scaling).  Rank 0 prints ONE JSON line.
+dropout 0.0 (--dropout; the YAML trains with 0.1, see the "dropout" key of the line), per-GPU batch
+--batch (default 512 sequences, the YAML's own batch_size, = 262,144 tokens per GPU per step; weak
+scaling).  Rank 0 prints ONE JSON line.
+
+The line's "roofline" block is about the kernel class the step spends most of its time in (the
+256-row MFMA GEMM in all its roles); "roofline_by_kernel" lists every instrumented class.  Both
+come from HIP events recorded around each launch on the launching stream inside the timed region
+(src/ops.py KERNEL_EVENTS); LDM_BENCH_EVENTS=0 switches the events off (A/B of their cost).
 """
 from __future__ import annotations
 
@@ -19,12 +26,11 @@ import gc
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 import types
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -42,6 +48,19 @@ CONFIGS = {
     "tiny": dict(vocab_size=200, d_model=64, nhead=2, num_layers=2, dim_feedforward=128),
 }
 
+# kernel class -> (what bounds it, printable name)
+CLASSES = {
+    "gemm.fwd": ("mfma", "gemm256_k forward (qkv, out+residual, gate/up+SwiGLU, down+residual, LM head on masked rows)"),
+    "gemm.dx": ("mfma", "gemm256_k input gradients (incl. the SwiGLU-backward epilogue variant)"),
+    "gemm.dw": ("mfma", "gemm256_k weight+bias gradients (split-K, fp32 atomics)"),
+    "attn.fwd": ("mfma", "attention forward"),
+    "attn.bwd": ("mfma", "attention backward (dQ and dK/dV kernels, one entry point)"),
+    "rmsnorm.fwd": ("hbm", "rmsnorm_fwd8_k"),
+    "rmsnorm.bwd": ("hbm", "rmsnorm_bwd8_k + dw second stage"),
+    "rope": ("hbm", "rope_qk8_k"),
+    "ce": ("hbm", "ce_fwd_grad_k (one-pass masked CE over the compact logits)"),
+}
+
 
 def train_flops_per_token(c, seq):
     """3 * (2*N_mm + 4*S*d*L), N_mm = L*(4d^2 + 3dF) + d*V: the algorithmic matmul+attention work."""
@@ -51,6 +70,7 @@ def train_flops_per_token(c, seq):
 
 
 def synthetic_tokens(batch, seq, vocab, seed):
+    import torch
     g = torch.Generator().manual_seed(seed)
     lo = 1000 if vocab > 2000 else 110
     ids = torch.randint(lo, vocab, (batch, seq), generator=g, dtype=torch.int64)
@@ -62,6 +82,7 @@ def synthetic_tokens(batch, seq, vocab, seed):
 def cpu_baseline(cfg, seq, steps=3):
     """The CPU restatement of the reference step (oracle/step_oracle.py: fp32, torch CPU ops,
     autograd backward, AdamW) on a bounded sample: B=4 sequences per step."""
+    import torch
     from oracle import step_oracle as so
     ncores = os.cpu_count() or 1
     threads = min(ncores, int(os.environ.get("OMP_NUM_THREADS", ncores)))
@@ -93,6 +114,47 @@ def cpu_baseline(cfg, seq, steps=3):
             "sample": f"{steps} timed steps (median) of B={B}, S={seq}, fp32, oracle/step_oracle.py + AdamW"}
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` typed as a plain command: start the N ranks as children (one process
+    per GPU under torch.distributed.run, the launcher the reference's README reaches through
+    ``accelerate launch``) and hand back their exit status.  This parent never touches the GPU -- it
+    does not even import torch -- so the ranks are ordinary children of a GPU-free process; rank 0
+    prints the single JSON line straight to the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def summarize_events(events, steps):
+    """KERNEL_EVENTS -> {class: {launches_per_step, ms_per_step, work_per_step}} (device-side counts read back)."""
+    out = {}
+    for tag, lst in events.items():
+        if not lst:
+            continue
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in lst)
+        work = sum(w * (float(c.item()) if c is not None else 1.0) for _, _, w, c in lst)
+        out[tag] = {"launches_per_step": len(lst) / steps, "ms_per_step": ms / steps, "work_per_step": work / steps}
+    return out
+
+
+def committed_traffic(cfg_name, dtype, batch, seq):
+    """Memory-side bytes per launch of the GEMM class from the committed PMC passes
+    (profiles/r2_gemm_traffic.json, made by scripts/gpu_pmc_bench.sh at the bench shape); None if this
+    run's shape is not the one that was profiled."""
+    path = os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tj = json.load(open(path))
+    if (tj.get("config"), tj.get("dtype"), tj.get("batch"), tj.get("seq")) != (cfg_name, dtype, batch, seq):
+        return None
+    return tj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,12 +167,22 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.0,
-                    help="residual dropout probability (the two per-layer residual dropouts; the fused "
-                         "attention kernel applies none to the attention probabilities)")
+                    help="dropout probability of all three dropouts of the encoder layer (attention "
+                         "probabilities inside the attention kernels, and the two residual dropouts); "
+                         "configs/default.yaml:13 trains with 0.1, parity and the headline number use 0.0")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--objective", default="reference", choices=["reference", "paper"],
+                    help="reference: one scalar t per step, unweighted mean over masked positions; paper: "
+                         "per-sequence t ~ U(eps,1), 1/t weights, B*L normaliser")
     ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
                     help="hip: src.optim.FusedAdamW (one HIP pass, weight copies refreshed in it); torch: torch.optim.AdamW(fused=True)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
 
     if os.environ.get("LDM_FAULT_TIMEOUT"):     # debugging aid: dump python stacks if the run stalls
         import faulthandler
@@ -119,11 +191,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("LDM_DP_SAME_GPU"):      # rehearsal of the multi-rank path on a one-GPU box
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         backend = os.environ.get("LDM_DP_BACKEND", "nccl")
         if backend == "nccl":
@@ -132,7 +205,7 @@ def main():
             dist.init_process_group(backend)
 
     from src import ops
-    from src.dp import HipAccelerator
+    from src.dp import GradBucketDataParallel, HipAccelerator
     from src.masking_strategy import create_masking_strategy
     from src.model import DiffusionLanguageModel
     from src.trainer import DiffusionLanguageModelTrainer
@@ -154,6 +227,7 @@ def main():
     else:
         opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, fused=True)
     trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+    trainer.objective = args.objective
     model.train()
 
     ids, att = synthetic_tokens(args.batch, args.seq, cfg["vocab_size"], 1234 + rank)
@@ -163,6 +237,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # how many ranks does the collective see?  (an all-reduce of ones over the gradient backend)
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=dev) if backend == "nccl" else torch.ones(1)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     last = 0.0
     # loss_value(): the host reads every step's loss before it starts the next one, as the
@@ -175,16 +256,18 @@ def main():
     # a full collection over it pauses the host for ~80 ms, long enough to drain the GPU queue
     gc.collect()
     gc.freeze()
-    ops.GEMM_EVENTS = {"head.fwd": []}
+    want_events = os.environ.get("LDM_BENCH_EVENTS", "1") != "0" and rank == 0
+    if want_events:
+        ops.KERNEL_EVENTS = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = read(trainer._step(batch))
     sync()
     elapsed = time.perf_counter() - t0
-    events = ops.GEMM_EVENTS["head.fwd"]
-    ops.GEMM_EVENTS = None
+    events = ops.KERNEL_EVENTS or {}
+    ops.KERNEL_EVENTS = None
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -192,27 +275,36 @@ def main():
         tokens = args.batch * args.seq * world * args.steps
         tps = tokens / elapsed
         fpt = train_flops_per_token(cfg, args.seq)
-        # dominant kernel: the LM-head forward GEMM ([B*S, d] x [d, V]), one launch per step
-        ms = [e[0].elapsed_time(e[1]) for e in events]
-        # fused head loss: the launch covers only the rows the loss reads (count on the device)
-        fl = [e[2] * (float(e[3].item()) if len(e) > 3 else 1.0) for e in events]
-        flops = sum(fl) / max(len(fl), 1)
-        avg_ms = sum(ms) / max(len(ms), 1)
-        achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        head_rows = (sum(float(e[3].item()) for e in events) / (len(events) * args.batch * args.seq)
-                     if events and len(events[0]) > 3 else 1.0)
+        per = summarize_events(events, args.steps)
+        by_kernel = []
+        for tag, (bound, name) in CLASSES.items():
+            if tag not in per:
+                continue
+            e = per[tag]
+            sec = e["ms_per_step"] * 1e-3
+            if bound == "mfma":
+                ach, peak, unit = e["work_per_step"] / sec / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = e["work_per_step"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+            by_kernel.append({"class": tag, "kernel": name, "bound": bound, "launches_per_step": e["launches_per_step"],
+                              "ms_per_step": e["ms_per_step"], "work_per_step": e["work_per_step"],
+                              "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+        # the class the step spends most of its time in: every role of the 256-row MFMA GEMM together
+        gemm = [k for k in by_kernel if k["class"].startswith("gemm.")]
+        g_ms = sum(k["ms_per_step"] for k in gemm)
+        g_fl = sum(k["work_per_step"] for k in gemm)
+        g_n = sum(k["launches_per_step"] for k in gemm)
+        attn_fl = sum(k["work_per_step"] for k in by_kernel if k["class"].startswith("attn."))
+        attn_ms = sum(k["ms_per_step"] for k in by_kernel if k["class"].startswith("attn."))
+        head_rows = 1.0
+        hf = [e for e in events.get("gemm.fwd", []) if e[3] is not None]
+        if hf:
+            head_rows = sum(float(e[3].item()) for e in hf) / (len(hf) * args.batch * args.seq)
         d_, V_ = cfg["d_model"], cfg["vocab_size"]
         # work actually executed: the three LM-head GEMMs run on the participating rows only
         fpt_exec = fpt - 6.0 * d_ * V_ * (1.0 - head_rows)
-        # memory-side bytes of that kernel per launch, from the committed PMC passes (per-row rates
-        # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scaled to this run's row count)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_head_fwd_traffic.json")
-        if os.path.exists(tpath) and args.config == "default" and args.dtype == "bf16":
-            tj = json.load(open(tpath))
-            rows_m = sum(l["rows"] for l in tj["launches"])
-            per_row = sum(l["fetch_kib_raw"] * tj["fetch_correction"] + l["write_kib"] for l in tj["launches"]) * 1024.0 / rows_m
-            traffic = per_row * head_rows * args.batch * args.seq
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        tj = committed_traffic(args.config, args.dtype, args.batch, args.seq)
         out = {
             "metric": "masked-diffusion train tokens/sec (node)", "value": tps, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -221,19 +313,30 @@ def main():
             "config": {"workload": f"configs/default.yaml model, seq {args.seq}" if args.config == "default"
                        else f"{args.config} model, seq {args.seq}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": args.seq,
-                       "parallelism": f"dp{world}", "dropout": args.dropout, "optimizer": "AdamW(lr=5e-4, wd=0.1)",
-                       **cfg},
+                       "parallelism": f"dp{world}", "dropout": args.dropout, "objective": args.objective,
+                       "optimizer": "AdamW(lr=5e-4, wd=0.1)", **cfg},
+            "ranks_seen": ranks_seen,
+            "grad_buckets": model.num_buckets if isinstance(model, GradBucketDataParallel) else 0,
+            "dp_backend": backend,
             "loss_last_step": last,
             "train_flops_per_token": fpt,
-            # fraction of the bf16 MFMA peak: with the flops of the reference's step (LM head on every
-            # position) and with the flops executed here (LM head on the rows the loss reads)
-            "mfma_fraction_algorithmic": tps * fpt / (world * PEAK_BF16_TFLOPS * 1e12),
+            # fraction of the bf16 MFMA peak: with the flops executed here (LM head on the rows the loss
+            # reads) -- the figure to quote -- and with the flops of the reference's step (LM head on
+            # every position), which credits work that is not done
             "mfma_fraction_of_step": tps * fpt_exec / (world * PEAK_BF16_TFLOPS * 1e12),
+            "mfma_fraction_algorithmic": tps * fpt / (world * PEAK_BF16_TFLOPS * 1e12),
             "executed_flops_per_token": fpt_exec, "lm_head_rows_fraction": head_rows,
-            "roofline": {"kernel": "gemm256_k (LM-head forward GEMM over the rows the loss reads)", "bound": "mfma",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "flops_per_launch": flops, "avg_launch_ms": avg_ms},
+            "mfma_fraction_attn_plus_gemm": ((g_fl + attn_fl) / ((g_ms + attn_ms) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
+                                             if g_ms + attn_ms > 0 else None),
+            "roofline": {"kernel": "gemm256_k, all variants (the time-dominant kernel class of the step)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": tj["gemm_bytes_per_launch"] if tj else None,
+                         "flops_per_launch": g_fl / g_n if g_n else 0.0,
+                         "avg_launch_ms": g_ms / g_n if g_n else 0.0,
+                         "launches_per_step": g_n, "ms_per_step": g_ms,
+                         "share_of_step": g_ms / (1e3 * elapsed / args.steps) if elapsed > 0 else None},
+            "roofline_by_kernel": by_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.seq)

@@ -172,8 +172,11 @@ int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
  * reference's masked_fill(-inf) at :271-274).  q is expected pre-scaled.
  * q, k, v are read from a fused [B*S, 3*H*hd] activation (ld_qkv elements per row;
  * q at column 0, k at H*hd, v at 2*H*hd); o is [B*S, H*hd] (ld_o).
- * `saved` keeps what backward needs: BF16: fp32 log-sum-exp [B,H,S];
- * F32: the probabilities [B,H,S,S].  Size: ldm_attn_saved_bytes().
+ * `saved` keeps what backward needs: BF16: fp32 log-sum-exp [B,H,S] followed by the bf16
+ * rounding residual of o (o_exact - o, [B*S, H*hd]; the backward forms rowsum(do * o) from o plus
+ * this residual -- with the rounded o alone the q/k gradients of deep layers carry about three times
+ * the error of the reference under bf16 autocast); F32: the probabilities [B,H,S,S].
+ * Size: ldm_attn_saved_bytes().  `saved` must be 16-byte aligned.
  * Backward writes dq,dk,dv into dqkv (same layout as qkv) from do_ and o.
  * ws: ldm_attn_bwd_ws_bytes() bytes of scratch. */
 int64_t ldm_attn_saved_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd);
@@ -283,15 +286,18 @@ int ldm_colsum_rows_dyn(const void *X, int dtype, int64_t M, int64_t N, int64_t 
  * participating rows only): masked_cross_entropy_loss (src/loss.py:12-28) and the backward of
  * F.cross_entropy (src/loss.py:22 under autograd) together.  Rows 0..*count-1 of logits
  * [rows_alloc, ld] all take part, targets[i] is the label of compact row i.  Each row is read once:
- *   row_tmp[i] = logsumexp(row) - row[target],   row := (softmax(row) - onehot(target)) / norm
- * with norm = *count (norm_mode 0) or norm_T (norm_mode 1); columns V..ld-1 are written as zero and
+ *   row_tmp[i] = w_i (logsumexp(row) - row[target]),   row := w_i (softmax(row) - onehot(target)) / norm
+ * with w_i = row_weight ? row_weight[i] : 1 (reference: 1; the paper-form objective hands in 1/t of the
+ * row's sequence) and norm = *count (norm_mode 0, the reference's mean over masked positions) or norm_T
+ * (norm_mode 1, the paper's B*L); columns V..ld-1 are written as zero and
  * rows *count..roundup(*count, 64)-1 are zeroed.  loss_out[0] = sum_i row_tmp[i] / norm (0 when
  * *count == 0), count_out[0] = *count.  The gradient left in logits is for an upstream gradient of
  * 1; ldm_scale_rows_dev applies another one (x[i, :ncols] *= *scale for i < *count; a launch that
  * returns at once when *scale == 1).  V up to 131072; 16-byte aligned rows (ld % 8 == 0). */
 int ldm_ce_fwd_grad(void *logits, int dtype, int64_t ld, int64_t rows_alloc, int64_t V,
                     const int64_t *targets, const int32_t *count, int norm_mode, float norm_T,
-                    float *row_lse, float *row_tmp, float *loss_out, float *count_out, void *stream);
+                    const float *row_weight, float *row_lse, float *row_tmp, float *loss_out, float *count_out,
+                    void *stream);
 int ldm_scale_rows_dev(void *x, int dtype, int64_t ld, int64_t rows_alloc, int64_t ncols,
                        const int32_t *count, const float *scale, void *stream);
 

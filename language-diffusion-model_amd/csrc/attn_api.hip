@@ -2,14 +2,21 @@
 #include "common.h"
 #include "attn.h"
 
+// BF16 `saved`: fp32 log-sum-exp [B,H,S], then (256-byte aligned) the bf16 rounding residual of O,
+// [B*S, H*hd], which the backward adds to O when it forms delta = rowsum(dO * O)
+static int64_t lse_bytes(int64_t batch, int64_t nhead, int64_t seq) {
+  return (batch * nhead * seq * (int64_t)sizeof(float) + 255) / 256 * 256;
+}
+
 extern "C" int64_t ldm_attn_saved_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd) {
-  (void)hd;
-  if (dtype == LDM_BF16) return batch * nhead * seq * (int64_t)sizeof(float);
+  if (dtype == LDM_BF16) return lse_bytes(batch, nhead, seq) + batch * seq * nhead * hd * 2;
   return batch * nhead * seq * seq * (int64_t)sizeof(float);
 }
 
 extern "C" int64_t ldm_attn_bwd_ws_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd) {
-  return ldm_attn_saved_bytes(dtype, batch, nhead, seq, hd);
+  (void)hd;
+  if (dtype == LDM_BF16) return batch * nhead * seq * (int64_t)sizeof(float);   // delta
+  return batch * nhead * seq * seq * (int64_t)sizeof(float);
 }
 
 // keep threshold of the dropout hash for probability p (see common.h); -1 for p outside [0, 1)
@@ -29,7 +36,7 @@ static int attn_fwd_impl(int dtype, const void *qkv, int64_t ld_qkv, const uint8
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LDM_BF16)
     return ldm_flash_fwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (bf16_t *)o, ld_o,
-                              (float *)saved, thresh, seed, s);
+                              (float *)saved, (bf16_t *)((char *)saved + lse_bytes(batch, nhead, seq)), thresh, seed, s);
   if (dtype == LDM_F32)
     return ldm_attn_fwd_f32((const float *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (float *)o, ld_o,
                             (float *)saved, (float *)ws, thresh, seed, s);
@@ -63,8 +70,9 @@ static int attn_bwd_impl(int dtype, const void *qkv, int64_t ld_qkv, const uint8
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LDM_BF16)
     return ldm_flash_bwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (const bf16_t *)o,
-                              (const bf16_t *)do_, ld_o, (const float *)saved, (bf16_t *)dqkv, (float *)ws, rope_cos,
-                              rope_sin, rope_scale, thresh, seed, s);
+                              (const bf16_t *)do_, ld_o, (const float *)saved,
+                              (const bf16_t *)((const char *)saved + lse_bytes(batch, nhead, seq)), (bf16_t *)dqkv,
+                              (float *)ws, rope_cos, rope_sin, rope_scale, thresh, seed, s);
   if (rope_cos) return LDM_E_SHAPE;
   if (dtype == LDM_F32)
     return ldm_attn_bwd_f32((const float *)qkv, ld_qkv, batch, nhead, seq, hd, (const float *)do_, ld_o,

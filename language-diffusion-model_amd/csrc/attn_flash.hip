@@ -44,6 +44,12 @@ struct FArgs {
   int B, H, S, hd;
   bf16_t *o; const bf16_t *o_in; const bf16_t *dout; int64_t ld_o;
   float *lse; const float *lse_in;
+  // O - bf16(O), itself rounded to bf16, [B*S, H*hd] contiguous: written by the forward, read by the dQ
+  // kernel, so that delta = rowsum(dO * O) is formed from O to ~16 mantissa bits.  With the stored
+  // bf16 O alone the error of delta is the SAME for every key of a query row and does not average out
+  // over the keys in dQ: the q/k projection gradients of deep layers then carry 3x the error the
+  // reference has under bf16 autocast (measured; its softmax backward sums P * dP in fp32).
+  bf16_t *o_lo; const bf16_t *o_lo_in;
   bf16_t *dqkv; float *delta;
   unsigned long long *timing;   // experiment builds only
   // optional (backward): fp32 [S, hd/2] rotary tables; dq and dk are then written as gradients
@@ -248,6 +254,42 @@ __device__ __forceinline__ void unrope_acc(f16_t (&acc)[AT<DP>::ND], float scale
   }
 }
 
+// O_lo = O - bf16(O) of a wave's 32 x DP output tile (see FArgs::o_lo); same store path as O itself
+template <int DP>
+__device__ __forceinline__ void store_rounding_residual(const FArgs &a, f16_t (&oacc)[AT<DP>::ND], float inv_l, char *wlds,
+                                                        int b, int head, int q0, int q, int lane, int half) {
+#pragma unroll
+  for (int i = 0; i < AT<DP>::ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = oacc[i][r] * inv_l;
+      oacc[i][r] = v - bf16_to_f32(f32_to_bf16(v));
+    }
+  const int64_t D = (int64_t)a.H * a.hd;
+  if (aligned_to_dev(a.o_lo, 16))
+    store_tile_lds<DP>(wlds, a.o_lo + ((int64_t)b * a.S + q0) * D + (int64_t)head * a.hd, D, oacc, 1.0f, lane, a.S - q0, a.hd);
+  else if (q < a.S)
+    store_rows<DP>(a.o_lo + ((int64_t)b * a.S + q) * D + (int64_t)head * a.hd, oacc, 1.0f, half, a.hd);
+}
+
+// sum over this lane's head-dim slice of o_lo[row] * dO[row] (see FArgs::o_lo); 0 without the residual
+template <int NK>
+__device__ __forceinline__ float delta_residual(const bf16_t *o_lo, const bf8_t (&dof)[NK], int64_t row_off, int half, int hd) {
+  float acc = 0.f;
+  if (o_lo) {
+    const bf16_t *p = o_lo + row_off + 8 * half;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      if (16 * kk + 8 * half < hd) {
+        const bf8_t olf = __builtin_bit_cast(bf8_t, *reinterpret_cast<const uint4 *>(p + 16 * kk));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)olf[j], (float)dof[kk][j], acc);
+      }
+    }
+  }
+  return acc;
+}
+
 // --------------------------------------------------------------------------- forward
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
@@ -408,11 +450,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
   if (q < S && half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
   {
     const int q0 = blk.blk * 128 + wave * 32;   // the loop ended with a barrier: the K/V tiles are dead
+    const float inv_l = 1.0f / ltot;
     if (a.ld_o % 8 == 0 && aligned_to_dev(a.o, 16))
       store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.o + ((int64_t)b * S + q0) * a.ld_o + (int64_t)head * hd, a.ld_o,
-                         oacc, 1.0f / ltot, lane, S - q0, hd);
+                         oacc, inv_l, lane, S - q0, hd);
     else if (q < S)
-      store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
+      store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, inv_l, half, hd);
+    if (a.o_lo) store_rounding_residual<DP>(a, oacc, inv_l, smem + wave * 32 * T::RSTR, b, head, q0, q, lane, half);
   }
 #ifdef LDM_ATTN_TIMING
   if (a.timing && tid == 0 && blockIdx.x == 8) {
@@ -681,11 +725,13 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
   if (q < S && half == 0) a.lse[((int64_t)b * a.H + head) * S + q] = m + logf(ltot);
   {
     const int q0 = blk.blk * 128 + wave * 32;
+    const float inv_l = 1.0f / ltot;
     if (a.ld_o % 8 == 0 && aligned_to_dev(a.o, 16))
       store_tile_lds<DP>(smem + wave * 32 * T::RSTR, a.o + ((int64_t)b * S + q0) * a.ld_o + (int64_t)head * hd, a.ld_o,
-                         oacc, 1.0f / ltot, lane, S - q0, hd);
+                         oacc, inv_l, lane, S - q0, hd);
     else if (q < S)
-      store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, 1.0f / ltot, half, hd);
+      store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, inv_l, half, hd);
+    if (a.o_lo) store_rounding_residual<DP>(a, oacc, inv_l, smem + wave * 32 * T::RSTR, b, head, q0, q, lane, half);
   }
 #ifdef LDM_ATTN_TIMING
   if (a.timing && tid == 0 && blockIdx.x == 8) {
@@ -735,6 +781,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
+  dsum += delta_residual<T::NK>(a.o_lo_in, dof, (int64_t)b * S * D + (int64_t)head * hd + (int64_t)qc * D, half, hd);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
@@ -1011,6 +1058,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
+  dsum += delta_residual<T::NK>(a.o_lo_in, dof, (int64_t)b * S * D + (int64_t)head * hd + (int64_t)qc * D, half, hd);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
@@ -1318,9 +1366,10 @@ int check(const FArgs &a) {
 }  // namespace
 
 int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
-                       int64_t hd, bf16_t *o, int64_t ld_o, float *lse, unsigned drop_thresh, uint64_t seed,
-                       hipStream_t s) {
+                       int64_t hd, bf16_t *o, int64_t ld_o, float *lse, bf16_t *o_lo, unsigned drop_thresh,
+                       uint64_t seed, hipStream_t s) {
   FArgs a{};
+  a.o_lo = o_lo;
   a.drop_thresh = drop_thresh; a.drop_inv = (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh));
   a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
   a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
@@ -1343,9 +1392,10 @@ int ldm_flash_fwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
 
 int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
                        int64_t hd, const bf16_t *o, const bf16_t *dout, int64_t ld_o, const float *lse,
-                       bf16_t *dqkv, float *delta, const float *rope_cos, const float *rope_sin, float rope_scale,
-                       unsigned drop_thresh, uint64_t seed, hipStream_t s) {
+                       const bf16_t *o_lo, bf16_t *dqkv, float *delta, const float *rope_cos, const float *rope_sin,
+                       float rope_scale, unsigned drop_thresh, uint64_t seed, hipStream_t s) {
   FArgs a{};
+  a.o_lo_in = o_lo;
   a.drop_thresh = drop_thresh; a.drop_inv = (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh));
   a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
   if (rope_cos) {   // fused un-rotation: head dim must fill its template and the tables must be 16-byte aligned

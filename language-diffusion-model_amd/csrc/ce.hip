@@ -478,7 +478,8 @@ __device__ __forceinline__ float block_reduce(float v, float *sm, bool is_max) {
 template <typename T, int BT, int NV>
 __global__ __launch_bounds__(BT) void ce_fwd_grad_k(T *logits, int64_t ld, int64_t V, int64_t rows_alloc,
                                                     const int64_t *targets, const int *count, float norm_T,
-                                                    int norm_mode, float *row_lse, float *row_loss) {
+                                                    int norm_mode, const float *row_weight, float *row_lse,
+                                                    float *row_loss) {
   __shared__ float sm[BT / 64];
   __shared__ float sm_xt;
   const int cnt = count[0];
@@ -536,9 +537,11 @@ __global__ __launch_bounds__(BT) void ce_fwd_grad_k(T *logits, int64_t ld, int64
       }
     sum = block_reduce<BT>(sum, sm, false);      // its barriers also publish sm_xt
     const float lse = mx + logf(sum);
+    const float wr = row_weight ? row_weight[i] : 1.0f;   // per-row weight (1/t of the row's sequence)
+    const float winv = wr * inv;
     if (threadIdx.x == 0) {
       row_lse[i] = lse;
-      row_loss[i] = lse - (tvec >= 0 ? sm_xt : 0.f);
+      row_loss[i] = wr * (lse - (tvec >= 0 ? sm_xt : 0.f));
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) v[u].pin();
@@ -548,11 +551,11 @@ __global__ __launch_bounds__(BT) void ce_fwd_grad_k(T *logits, int64_t ld, int64
         const int c = threadIdx.x + u * BT;
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = __expf(v[u].get(j) - lse) * inv;
+        for (int j = 0; j < 8; ++j) o[j] = __expf(v[u].get(j) - lse) * winv;
         if (c == tvec) {
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (tj == j) o[j] -= inv;
+            if (tj == j) o[j] -= winv;
         }
         if (c < nv) Raw8<T>::store(row + (int64_t)c * 8, o);
       }
@@ -744,17 +747,17 @@ extern "C" int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int
 
 template <typename T>
 static int ce_fwd_grad_launch(void *logits, int64_t ld, int64_t rows_alloc, int64_t V, const int64_t *targets,
-                              const int32_t *count, float norm_T, int norm_mode, float *row_lse, float *row_tmp,
-                              hipStream_t s) {
+                              const int32_t *count, float norm_T, int norm_mode, const float *row_weight,
+                              float *row_lse, float *row_tmp, hipStream_t s) {
   const int64_t nv = (V + 7) / 8;
   if (nv <= 256 * 16) {
     const unsigned grid = (unsigned)(rows_alloc < 2048 ? rows_alloc : 2048);
     hipLaunchKernelGGL((ce_fwd_grad_k<T, 256, 16>), dim3(grid), dim3(256), 0, s, (T *)logits, ld, V, rows_alloc, targets,
-                       count, norm_T, norm_mode, row_lse, row_tmp);
+                       count, norm_T, norm_mode, row_weight, row_lse, row_tmp);
   } else if (nv <= 1024 * 16) {
     const unsigned grid = (unsigned)(rows_alloc < 512 ? rows_alloc : 512);
     hipLaunchKernelGGL((ce_fwd_grad_k<T, 1024, 16>), dim3(grid), dim3(1024), 0, s, (T *)logits, ld, V, rows_alloc,
-                       targets, count, norm_T, norm_mode, row_lse, row_tmp);
+                       targets, count, norm_T, norm_mode, row_weight, row_lse, row_tmp);
   } else {
     return LDM_E_SHAPE;
   }
@@ -764,7 +767,8 @@ static int ce_fwd_grad_launch(void *logits, int64_t ld, int64_t rows_alloc, int6
 
 extern "C" int ldm_ce_fwd_grad(void *logits, int dtype, int64_t ld, int64_t rows_alloc, int64_t V,
                                const int64_t *targets, const int32_t *count, int norm_mode, float norm_T,
-                               float *row_lse, float *row_tmp, float *loss_out, float *count_out, void *stream) {
+                               const float *row_weight, float *row_lse, float *row_tmp, float *loss_out,
+                               float *count_out, void *stream) {
   if (rows_alloc < 0 || V <= 0 || ld < V) return LDM_E_BADARG;
   if (!targets || !count || !loss_out || !count_out) return LDM_E_BADARG;
   if (norm_mode != 0 && norm_mode != 1) return LDM_E_BADARG;
@@ -775,8 +779,8 @@ extern "C" int ldm_ce_fwd_grad(void *logits, int dtype, int64_t ld, int64_t rows
     const size_t esz = dtype == LDM_F32 ? 4 : 2;
     if (!aligned_to(logits, 8 * esz) || ld % 8) return LDM_E_ALIGN;
     int rc;
-    if (dtype == LDM_F32) rc = ce_fwd_grad_launch<float>(logits, ld, rows_alloc, V, targets, count, norm_T, norm_mode, row_lse, row_tmp, s);
-    else if (dtype == LDM_BF16) rc = ce_fwd_grad_launch<bf16_t>(logits, ld, rows_alloc, V, targets, count, norm_T, norm_mode, row_lse, row_tmp, s);
+    if (dtype == LDM_F32) rc = ce_fwd_grad_launch<float>(logits, ld, rows_alloc, V, targets, count, norm_T, norm_mode, row_weight, row_lse, row_tmp, s);
+    else if (dtype == LDM_BF16) rc = ce_fwd_grad_launch<bf16_t>(logits, ld, rows_alloc, V, targets, count, norm_T, norm_mode, row_weight, row_lse, row_tmp, s);
     else return LDM_E_DTYPE;
     if (rc) return rc;
   }

@@ -109,7 +109,7 @@ extern "C" int ldm_gemm_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *
   return ldm_gemm_mfma256_bf16_swiglu_fwd(T, F, K, x, ldx, W12, ldw, bias, ag, ld_ag, h, ld_h, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 12; }
+extern "C" int ldm_abi_version(void) { return 13; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 12   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 13   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -73,7 +73,7 @@ SIGNATURES = {
     "ldm_remask_apply": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "ldm_ce_bwd_compact": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _i64, _vp]),
-    "ldm_ce_fwd_grad": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "ldm_ce_fwd_grad": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldm_scale_rows_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ldm_adamw_step": (_i32, [C.POINTER(AdamWTensor), _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "ldm_collate_pad": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

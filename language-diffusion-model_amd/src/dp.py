@@ -210,8 +210,11 @@ class HipAccelerator:
                     if isinstance(model, GradBucketDataParallel) and model._active:
                         model.defer_scale = True
                         o.grad_scale = 1.0 / model.world_size
-            elif isinstance(o, torch.optim.Optimizer) and not getattr(o, "_ldm_epoch_hook", False):
-                # fused torch optimizers update parameters without moving their version counters
+            elif (isinstance(o, torch.optim.Optimizer) and not getattr(o, "_ldm_epoch_hook", False)
+                  and hasattr(o, "_optimizer_step_post_hooks")):
+                # fused torch optimizers update parameters without moving their version counters.  (Wrappers
+                # that never ran Optimizer.__init__ have no hook registry; the trainer marks the weight
+                # copies stale after their step() itself.)
                 from . import ops
                 o.register_step_post_hook(lambda *_a, **_k: ops.parameters_changed())
                 o._ldm_epoch_hook = True

@@ -46,13 +46,32 @@ class DiffusionLanguageModel(nn.Module):
         return logits, masked_input_ids, mask_indices
 
     def training_loss(self, input_ids: Tensor, attention_mask: Tensor | None = None,
-                      t: Tensor | None = None) -> Tensor:
+                      t: Tensor | None = None, *, objective: str = "reference", eps: float = 1e-3) -> Tensor:
         """The loss of one training step: forward() followed by variational_lower_bound_loss
         as the reference trainer composes them (src/trainer.py:126-134), with the LM head
         evaluated only at the positions the loss reads.  Consumes the python RNG exactly as
-        forward() does (one random.random() per call)."""
+        forward() does (one random.random() per call).
+
+        ``objective="reference"`` (default) is the reference's step: one scalar t per call, unweighted
+        mean over the masked positions.  ``objective="paper"`` is the LLaDA form, which the reference
+        does not implement (so it has no reference parity; it is checked against the CPU restatement
+        of the same formula): t_b ~ U(eps, 1) per sequence drawn inside the masking kernel (or the
+        per-sequence ``t`` handed in), every masked position of sequence b weighted by 1 / t_b, the
+        sum divided by B * L."""
+        if objective not in ("reference", "paper"):
+            raise ValueError(f"objective must be 'reference' or 'paper', got {objective!r}")
         if torch.is_grad_enabled():
             ops.begin_step()
+        if objective == "paper":
+            if t is None:
+                masked_input_ids, _, t_seq = self.masking_strategy.apply_per_sequence_mask(input_ids, eps=eps)
+            else:
+                t_seq = t.reshape(-1).to(device=input_ids.device, dtype=torch.float32)
+                if t_seq.numel() == 1:
+                    t_seq = t_seq.expand(input_ids.shape[0]).contiguous()
+                masked_input_ids, _ = self.masking_strategy.apply_random_mask(input_ids=input_ids, mask_prob=t_seq)
+            return self.transformer.masked_token_loss(masked_input_ids, input_ids, self.tokenizer.mask_token_id,
+                                                      attention_mask, seq_weight=1.0 / t_seq, normalize_by="tokens")
         if t is None:
             mask_prob = random.random()
         else:

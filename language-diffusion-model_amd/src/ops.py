@@ -17,17 +17,25 @@ from . import _native as N
 
 PAD_N = 64  # output columns of a projection are padded to this multiple in memory
 
-# data_ptr -> row stride of the gradient buffer most recently produced by the masked-CE
-# backward: its rows are padded to PAD_N columns and the padding is zero, so the
-# projection backward can consume it in place.
-_ZERO_PADDED: dict[int, int] = {}
-
 # LM-head backward over the participating rows only (no host sync: the row count stays on the
-# device).  _COMPACT_OK holds the data_ptr of projection outputs whose backward can take the
-# compact form; the masked-CE backward then leaves (dlogits_compact, rows, count, dummy) in
-# _COMPACT_GRAD under that pointer and hands autograd a zero-stride dummy of the logits' shape.
-_COMPACT_OK: set[int] = set()
-_COMPACT_GRAD: dict[int, tuple] = {}
+# device).  A _HeadLink is created per forward call of the vocabulary projection and travels WITH the
+# logits tensor (attribute ``_ldm_head_link`` of the tensor object the projection returns) to the
+# masked-CE that consumes it; the CE backward leaves its compact gradient (or the note that its dense
+# gradient buffer has zeroed padding columns) on the link, and the projection's backward -- which holds
+# the same link in its autograd context -- picks it up.  Nothing is keyed by addresses and nothing
+# outlives the tensors of one forward/backward pair, so several models, or a forward that is never
+# followed by its backward, cannot see each other's records.
+class _HeadLink:
+    __slots__ = ("y_ptr", "ld", "compact_ok", "grad", "zero_padded")
+
+    def __init__(self):
+        self.y_ptr = 0            # data pointer and row stride of the logits buffer this link describes
+        self.ld = 0
+        self.compact_ok = False   # the projection's backward can take compact gradient rows
+        self.grad = None          # (dlogits_compact, rows, count, dummy) left by the masked-CE backward
+        self.zero_padded = None   # (data_ptr, row stride) of a dense gradient whose padding columns are zero
+
+
 COMPACT_HEAD = True   # set False to force the dense LM-head backward
 FUSED_UNROPE = True     # rotary backward inside the attention-backward stores (False: separate pass)
 FUSED_BIAS_GRAD = True  # bias gradient from the weight-gradient GEMM (False: separate column-sum kernel)
@@ -148,31 +156,81 @@ def begin_step():
     ZERO_POOL.begin()
 
 
-# Optional per-launch timing for the benchmark: when set to a dict, every GEMM whose tag is a
-# key gets a pair of events recorded around its launch on the launching stream; the list
-# under the key collects (start, end, flops) triples.
-GEMM_EVENTS: dict | None = None
+# Optional per-launch timing for the benchmark: when set to a dict, every instrumented launch gets a
+# pair of events recorded around it on the launching stream (torch's current stream, the one the
+# kernels are enqueued on); KERNEL_EVENTS[tag] collects (start, end, work, count) tuples, where
+# ``work`` is the launch's algorithmic flops or bytes and ``count`` is None, or a device int32
+# tensor that the work is to be multiplied by (row counts that exist only on the device).
+KERNEL_EVENTS: dict | None = None
+
+
+class _Timed:
+    __slots__ = ("lst", "e0", "work", "count")
+
+    def __init__(self, tag, work, count=None):
+        self.lst = None
+        if KERNEL_EVENTS is not None:
+            self.lst = KERNEL_EVENTS.setdefault(tag, [])
+            self.work, self.count = work, count
+
+    def __enter__(self):
+        if self.lst is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.lst is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.lst.append((self.e0, e1, self.work, self.count))
+        return False
 
 
 def _gemm(in_dt, out_dt, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, res=None, ldr=0, alpha=1.0,
-          tag=None):
-    ev = GEMM_EVENTS.get(tag) if (GEMM_EVENTS is not None and tag is not None) else None
-    if ev is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    N.check(N.lib().ldm_gemm(N.dtype_code(in_dt), N.dtype_code(out_dt), ta, tb, m, n, k, alpha,
-                             a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
-                             N.ptr(bias), N.ptr(res), ldr, N.stream()), "ldm_gemm")
-    if ev is not None:
-        e1.record()
-        ev.append((e0, e1, 2.0 * m * n * k))
+          tag="gemm.fwd"):
+    with _Timed(tag, 2.0 * m * n * k):
+        N.check(N.lib().ldm_gemm(N.dtype_code(in_dt), N.dtype_code(out_dt), ta, tb, m, n, k, alpha,
+                                 a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
+                                 N.ptr(bias), N.ptr(res), ldr, N.stream()), "ldm_gemm")
+
+
+def _weight_bias_grads(pack, g, x_in, ld_x, T, k, dev, dt):
+    """dW [n_pad, k] and db [n_pad] of a projection from its output gradient g [T, n_pad] and its input
+    (one zeroed buffer; for bf16 one kernel produces both), split per packed parameter."""
+    n_pad = pack.n_pad
+    dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
+    dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
+    rc = -2
+    if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
+        with _Timed("gemm.dw", 2.0 * n_pad * k * T):
+            rc = N.lib().ldm_gemm_acc_rowsum(1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad, x_in.data_ptr(), ld_x,
+                                             dw.data_ptr(), k, db.data_ptr(), N.stream())
+        if rc not in (-2, -3):
+            N.check(rc, "ldm_gemm_acc_rowsum")
+    if rc in (-2, -3):
+        with _Timed("gemm.dw", 2.0 * n_pad * k * T):
+            N.check(N.lib().ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad,
+                                         x_in.data_ptr(), ld_x, dw.data_ptr(), k, N.stream()), "ldm_gemm_acc")
+        ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
+        N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
+                                   ws.data_ptr(), N.stream()), "ldm_colsum")
+    grads_w, grads_b = [], []
+    off = 0
+    for ne in pack.n_each:
+        grads_w.append(dw[off:off + ne])
+        grads_b.append(db[off:off + ne])
+        off += ne
+    return grads_w, grads_b
 
 
 class _PackedLinear(torch.autograd.Function):
-    """y[T, n] = x[T, k] @ Wpacked^T + b (+ residual);  grads for every packed weight/bias."""
+    """y[T, n] = x[T, k] @ Wpacked^T + b (+ residual);  grads for every packed weight/bias.
+
+    ``link`` (a _HeadLink or None) is filled in for the vocabulary projection: see _HeadLink."""
 
     @staticmethod
-    def forward(ctx, x2, residual, pack: PackedWeights, *params):
+    def forward(ctx, x2, residual, pack: PackedWeights, link, *params):
         N.require_device(x2)
         w, b = pack.get()
         T, k = x2.shape
@@ -185,30 +243,18 @@ class _PackedLinear(torch.autograd.Function):
             res = _rows2d(residual)
             if res.dtype != dt:
                 res = res.to(dt)
-        rc = -3
-        if (FUSED_SWIGLU_UP and getattr(pack, "swiglu_in", False) and res is None and dt == torch.bfloat16
-                and pack.n_pad == pack.n and len(pack.n_each) == 2 and pack.n_each[0] == pack.n_each[1]):
-            # gate/up projection of a SwiGLU: the activation h = a * silu(g) comes out of the same GEMM and is
-            # handed to swiglu_down (the call that follows) through _SWIGLU_H, keyed by this output
-            F = pack.n // 2
-            h = torch.empty(T, F, dtype=dt, device=x2.device)
-            rc = N.lib().ldm_gemm_swiglu_fwd(T, F, k, x2.data_ptr(), x2.stride(0), w.data_ptr(), k, N.ptr(b),
-                                             y.data_ptr(), pack.n_pad, h.data_ptr(), F, N.stream())
-            if rc not in (-2, -3):
-                N.check(rc, "ldm_gemm_swiglu_fwd")
-                _SWIGLU_H.clear()
-                _SWIGLU_H[y.data_ptr()] = (y, h)
-        if rc in (-2, -3):
-            _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
-                  res=res, ldr=res.stride(0) if res is not None else 0, tag=pack.name + ".fwd")
+        _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
+              res=res, ldr=res.stride(0) if res is not None else 0, tag="gemm.fwd")
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.save_for_backward(x2, w)
-        ctx.y_ptr = y.data_ptr()
-        if (COMPACT_HEAD and pack.compact_rows and dt == torch.bfloat16 and T >= 1024 and k >= 128 and k % 8 == 0
-                and x2.stride(0) % 4 == 0 and (pack.n_pad // 256) * ((k + 255) // 256) >= 200):
-            _COMPACT_OK.clear()
-            _COMPACT_OK.add(ctx.y_ptr)
+        ctx.link = link
+        if link is not None:
+            link.y_ptr, link.ld = y.data_ptr(), pack.n_pad
+            link.compact_ok = bool(
+                COMPACT_HEAD and pack.compact_rows and dt == torch.bfloat16 and T >= 1024 and k >= 128
+                and k % 8 == 0 and x2.stride(0) % 4 == 0 and (pack.n_pad // 256) * ((k + 255) // 256) >= 200
+                )
         return y[:, :pack.n] if pack.n != pack.n_pad else y
 
     @staticmethod
@@ -218,7 +264,10 @@ class _PackedLinear(torch.autograd.Function):
         dt = pack.dtype
         T, k = x2.shape
         n, n_pad = pack.n, pack.n_pad
-        entry = _COMPACT_GRAD.pop(ctx.y_ptr, None)
+        link = ctx.link
+        entry = None
+        if link is not None:
+            entry, link.grad = link.grad, None
         if entry is not None:
             dlc, rows, count, dummy = entry
             if gy.data_ptr() == dummy.data_ptr() and all(st == 0 for st in gy.stride()):
@@ -230,7 +279,10 @@ class _PackedLinear(torch.autograd.Function):
                 gy = gy + _expand_compact(dlc, rows, count, T, n_pad)[:, :n].view_as(gy)
         # gradient with the padded row stride and zero padding columns
         row_ok = gy.dtype == dt and gy.stride(-1) == 1 and (T == 1 or gy.stride(0) == n_pad)
-        if row_ok and (n_pad == n or _ZERO_PADDED.pop(gy.data_ptr(), None) == n_pad):
+        zp = None
+        if link is not None:
+            zp, link.zero_padded = link.zero_padded, None
+        if row_ok and (n_pad == n or zp == (gy.data_ptr(), n_pad)):
             g = gy
         else:
             g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
@@ -238,30 +290,10 @@ class _PackedLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, k, dtype=dt, device=g.device)
-            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag=pack.name + ".dx")
-        # dW and db share one zeroed buffer ([n_pad, k] then [n_pad]) and, for bf16, one kernel
-        dwb = ZERO_POOL.take(n_pad * k + n_pad, g.device)
-        dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
-        rc = -2
-        if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
-            rc = N.lib().ldm_gemm_acc_rowsum(1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad, x2.data_ptr(),
-                                             x2.stride(0), dw.data_ptr(), k, db.data_ptr(), N.stream())
-            if rc not in (-2, -3):
-                N.check(rc, "ldm_gemm_acc_rowsum")
-        if rc in (-2, -3):
-            N.check(N.lib().ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad,
-                                         x2.data_ptr(), x2.stride(0), dw.data_ptr(), k, N.stream()), "ldm_gemm_acc")
-            ws = torch.empty(N.lib().ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
-            N.check(N.lib().ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(),
-                                       ws.data_ptr(), N.stream()), "ldm_colsum")
-        grads_w, grads_b = [], []
-        off = 0
-        for ne in pack.n_each:
-            grads_w.append(dw[off:off + ne])
-            grads_b.append(db[off:off + ne])
-            off += ne
+            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
+        grads_w, grads_b = _weight_bias_grads(pack, g, x2, x2.stride(0), T, k, g.device, dt)
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
-        return (dx, dres, None, *grads_w, *grads_b)
+        return (dx, dres, None, None, *grads_w, *grads_b)
 
 
 def _backward_compact(ctx, x2, w, dlc, rows, count):
@@ -276,8 +308,9 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
     dx = None
     if ctx.needs_input_grad[0]:
         dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
-        rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, dlc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
-                                   None, count.data_ptr(), rows.data_ptr(), st)
+        with _Timed("gemm.dx", 2.0 * k * n_pad, count):
+            rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, dlc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
+                                       None, count.data_ptr(), rows.data_ptr(), st)
         if rc in (-2, -3):
             return None
         N.check(rc, "ldm_gemm_rows_dyn")
@@ -286,8 +319,9 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
                                 xc.data_ptr(), st), "ldm_gather_rows")
     dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
     dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
-    rc = lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, Tp, dlc.data_ptr(), n_pad, xc.data_ptr(), k, dw.data_ptr(), k,
-                               count.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None, st)
+    with _Timed("gemm.dw", 2.0 * n_pad * k, count):
+        rc = lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, Tp, dlc.data_ptr(), n_pad, xc.data_ptr(), k, dw.data_ptr(), k,
+                                   count.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None, st)
     if rc in (-2, -3):
         return None
     N.check(rc, "ldm_gemm_acc_kdyn")
@@ -302,7 +336,7 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
         grads_b.append(db[off:off + ne])
         off += ne
     COMPACT_STATS["used"] += 1
-    return (dx, None, None, *grads_w, *grads_b)
+    return (dx, None, None, None, *grads_w, *grads_b)
 
 
 _PackedLinear._backward_compact = staticmethod(_backward_compact)
@@ -311,8 +345,12 @@ _PackedLinear._backward_compact = staticmethod(_backward_compact)
 def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None) -> Tensor:
     shape = x.shape
     x2 = _rows2d(x)
-    y = _PackedLinear.apply(x2, residual, pack, *pack.weights, *pack.biases)
-    return y.reshape(*shape[:-1], pack.n) if y.is_contiguous() else y.view(*shape[:-1], pack.n)
+    link = _HeadLink() if pack.compact_rows else None
+    y = _PackedLinear.apply(x2, residual, pack, link, *pack.weights, *pack.biases)
+    out = y.reshape(*shape[:-1], pack.n) if y.is_contiguous() else y.view(*shape[:-1], pack.n)
+    if link is not None:
+        out._ldm_head_link = link    # read by masked_ce when THIS tensor object is handed to the loss
+    return out
 
 
 # ----------------------------------------------------------------------------
@@ -360,8 +398,9 @@ class _RMSNorm(torch.autograd.Function):
         y = torch.empty_like(xc)
         rstd = torch.empty(T, dtype=torch.float32, device=x.device)
         w = weight.detach().float().contiguous()
-        N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
-                                        y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+        with _Timed("rmsnorm.fwd", 2.0 * T * d * xc.element_size()):
+            N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
+                                            y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
         ctx.save_for_backward(xc, w, rstd)
         return y
 
@@ -376,9 +415,10 @@ class _RMSNorm(torch.autograd.Function):
         dx = torch.empty_like(xc)
         dw = torch.empty(d, dtype=torch.float32, device=xc.device)
         ws = torch.empty(N.lib().ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
-        N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), None, T, d,
-                                        N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                        N.stream()), "ldm_rmsnorm_bwd")
+        with _Timed("rmsnorm.bwd", 3.0 * T * d * xc.element_size()):
+            N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), None, T, d,
+                                            N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                            N.stream()), "ldm_rmsnorm_bwd")
         return dx, dw, None
 
 
@@ -400,8 +440,9 @@ class _RMSNormRes(torch.autograd.Function):
         y = torch.empty_like(xc)
         rstd = torch.empty(T, dtype=torch.float32, device=x.device)
         w = weight.detach().float().contiguous()
-        N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
-                                        y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+        with _Timed("rmsnorm.fwd", 2.0 * T * d * xc.element_size()):
+            N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
+                                            y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
         ctx.save_for_backward(xc, w, rstd)
         return y, xc.view_as(xc)
 
@@ -423,9 +464,10 @@ class _RMSNormRes(torch.autograd.Function):
         dx = torch.empty_like(xc)
         dw = torch.empty(d, dtype=torch.float32, device=xc.device)
         ws = torch.empty(N.lib().ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
-        N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
-                                        N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                        N.stream()), "ldm_rmsnorm_bwd")
+        with _Timed("rmsnorm.bwd", (4.0 if r is not None else 3.0) * T * d * xc.element_size()):
+            N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
+                                            N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                            N.stream()), "ldm_rmsnorm_bwd")
         return dx, dw, None
 
 
@@ -472,16 +514,78 @@ def swiglu_act(ag: Tensor) -> Tensor:
 FUSED_SWIGLU_DOWN = os.environ.get("LDM_FUSED_SWIGLU", "1") != "0"   # SwiGLU backward inside the w3 input-gradient GEMM
 # SwiGLU forward inside the gate/up projection GEMM (LDM_FUSED_SWIGLU_UP=0: separate elementwise pass)
 FUSED_SWIGLU_UP = os.environ.get("LDM_FUSED_SWIGLU_UP", "1") != "0"
-_SWIGLU_H: dict = {}   # output pointer of the gate/up projection -> (output, h); consumed by swiglu_down
+
+
+class _SwiGLUUp(torch.autograd.Function):
+    """(ag, h) = ([w1(x) | w2(x)], w1(x) * silu(w2(x))) from ONE GEMM over the packed gate/up weights
+    (src/transformer.py:91-93).  ``h`` is an auxiliary, non-differentiable output: the down projection
+    takes it as a ready-made operand and differentiates through ``ag`` (its backward re-derives
+    everything from ag), so the gradient of this node arrives through ``ag`` alone."""
+
+    @staticmethod
+    def forward(ctx, x2, pack: PackedWeights, *params):
+        N.require_device(x2)
+        w, b = pack.get()
+        T, k = x2.shape
+        dt = pack.dtype
+        if x2.dtype != dt:
+            x2 = x2.to(dt)
+        F = pack.n // 2
+        y = torch.empty(T, pack.n_pad, dtype=dt, device=x2.device)
+        h = torch.empty(T, F, dtype=dt, device=x2.device)
+        rc = -3
+        if FUSED_SWIGLU_UP and dt == torch.bfloat16 and pack.n_pad == pack.n:
+            with _Timed("gemm.fwd", 2.0 * T * pack.n_pad * k):
+                rc = N.lib().ldm_gemm_swiglu_fwd(T, F, k, x2.data_ptr(), x2.stride(0), w.data_ptr(), k, N.ptr(b),
+                                                 y.data_ptr(), pack.n_pad, h.data_ptr(), F, N.stream())
+            if rc not in (-2, -3):
+                N.check(rc, "ldm_gemm_swiglu_fwd")
+        if rc in (-2, -3):
+            _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b, tag="gemm.fwd")
+            ag = y if pack.n_pad == pack.n else y[:, :pack.n].contiguous()
+            N.check(N.lib().ldm_swiglu_fwd(ag.data_ptr(), T, F, N.dtype_code(dt), h.data_ptr(), N.stream()),
+                    "ldm_swiglu_fwd")
+        ctx.pack = pack
+        ctx.save_for_backward(x2, w)
+        ctx.mark_non_differentiable(h)
+        return (y[:, :pack.n] if pack.n != pack.n_pad else y), h
+
+    @staticmethod
+    def backward(ctx, gy, _gh):
+        x2, w = ctx.saved_tensors
+        pack = ctx.pack
+        dt = pack.dtype
+        T, k = x2.shape
+        n, n_pad = pack.n, pack.n_pad
+        if gy.dtype == dt and gy.stride(-1) == 1 and n_pad == n and (T == 1 or gy.stride(0) == n_pad):
+            g = gy
+        else:
+            g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
+            g[:, :n].copy_(gy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, k, dtype=dt, device=g.device)
+            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
+        grads_w, grads_b = _weight_bias_grads(pack, g, x2, x2.stride(0), T, k, g.device, dt)
+        return (dx, None, *grads_w, *grads_b)
+
+
+def swiglu_up(x: Tensor, pack: PackedWeights) -> tuple[Tensor, Tensor]:
+    """([a | g], a * silu(g)) for the packed [w1; w2] projection of x; both [..., 2F] / [..., F]."""
+    assert len(pack.weights) == 2 and pack.n_each[0] == pack.n_each[1]
+    shape = x.shape
+    ag, h = _SwiGLUUp.apply(_rows2d(x), pack, *pack.weights, *pack.biases)
+    return ag.reshape(*shape[:-1], pack.n), h
 
 
 class _SwiGLUDown(torch.autograd.Function):
     """y = (a * silu(g)) @ W3^T + b (+ residual) for ag = [a | g]: SwiGLU.forward after the two up
-    projections (src/transformer.py:93-95).  Backward never writes the gradient of the hidden
-    activation: dag comes out of the epilogue of the GEMM dy @ W3 (ldm_gemm_swiglu_bwd)."""
+    projections (src/transformer.py:93-95).  ``h`` = a * silu(g) when the caller already has it
+    (swiglu_up), else None.  Backward never writes the gradient of the hidden activation: dag comes
+    out of the epilogue of the GEMM dy @ W3 (ldm_gemm_swiglu_bwd)."""
 
     @staticmethod
-    def forward(ctx, ag, residual, pack: PackedWeights, *params):
+    def forward(ctx, ag, h, residual, pack: PackedWeights, *params):
         N.require_device(ag)
         lib = N.lib()
         w, b = pack.get()
@@ -494,13 +598,9 @@ class _SwiGLUDown(torch.autograd.Function):
         if ag2.stride(0) != F2:
             ag2 = ag2.contiguous()
         T = ag2.shape[0]
-        entry = _SWIGLU_H.pop(ag2.data_ptr(), None)
-        if entry is not None and entry[1].shape == (T, F) and entry[1].dtype == dt:
-            h = entry[1]      # formed in the epilogue of the projection that produced ag
-        else:
+        if h is None or tuple(h.shape) != (T, F) or h.dtype != dt or not h.is_contiguous():
             h = torch.empty(T, F, dtype=dt, device=ag2.device)
             N.check(lib.ldm_swiglu_fwd(ag2.data_ptr(), T, F, N.dtype_code(dt), h.data_ptr(), N.stream()), "ldm_swiglu_fwd")
-        _SWIGLU_H.clear()
         y = torch.empty(T, pack.n_pad, dtype=dt, device=ag2.device)
         res = None
         if residual is not None:
@@ -508,7 +608,7 @@ class _SwiGLUDown(torch.autograd.Function):
             if res.dtype != dt:
                 res = res.to(dt)
         _gemm(dt, dt, 0, 1, T, pack.n_pad, F, h, F, w, F, y, pack.n_pad, bias=b, res=res,
-              ldr=res.stride(0) if res is not None else 0, tag=pack.name + ".fwd")
+              ldr=res.stride(0) if res is not None else 0, tag="gemm.fwd")
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.out_shape = tuple(ag.shape[:-1]) + (pack.n,)
@@ -536,38 +636,27 @@ class _SwiGLUDown(torch.autograd.Function):
             dag = torch.empty_like(ag2)
             rc = -3
             if dt == torch.bfloat16 and FUSED_SWIGLU_DOWN:
-                rc = lib.ldm_gemm_swiglu_bwd(T, F, n_pad, g.data_ptr(), n_pad, w.data_ptr(), F, ag2.data_ptr(), 2 * F,
-                                             dag.data_ptr(), 2 * F, N.stream())
+                with _Timed("gemm.dx", 2.0 * T * F * n_pad):
+                    rc = lib.ldm_gemm_swiglu_bwd(T, F, n_pad, g.data_ptr(), n_pad, w.data_ptr(), F, ag2.data_ptr(), 2 * F,
+                                                 dag.data_ptr(), 2 * F, N.stream())
                 if rc not in (-2, -3):
                     N.check(rc, "ldm_gemm_swiglu_bwd")
             if rc in (-2, -3):
                 dh = torch.empty(T, F, dtype=dt, device=g.device)
-                _gemm(dt, dt, 0, 0, T, F, n_pad, g, n_pad, w, F, dh, F, tag=pack.name + ".dx")
+                _gemm(dt, dt, 0, 0, T, F, n_pad, g, n_pad, w, F, dh, F, tag="gemm.dx")
                 N.check(lib.ldm_swiglu_bwd(ag2.data_ptr(), dh.data_ptr(), T, F, N.dtype_code(dt), dag.data_ptr(), N.stream()),
                         "ldm_swiglu_bwd")
             dag = dag.view(ctx.ag_shape)
-        dwb = ZERO_POOL.take(n_pad * F + n_pad, g.device)
-        dw, db = dwb[:n_pad * F].view(n_pad, F), dwb[n_pad * F:]
-        rc = -2
-        if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
-            rc = lib.ldm_gemm_acc_rowsum(1, 0, n_pad, F, T, 1.0, g.data_ptr(), n_pad, h.data_ptr(), F, dw.data_ptr(), F,
-                                         db.data_ptr(), N.stream())
-            if rc not in (-2, -3):
-                N.check(rc, "ldm_gemm_acc_rowsum")
-        if rc in (-2, -3):
-            N.check(lib.ldm_gemm_acc(N.dtype_code(dt), 1, 0, n_pad, F, T, 1.0, g.data_ptr(), n_pad, h.data_ptr(), F,
-                                     dw.data_ptr(), F, N.stream()), "ldm_gemm_acc")
-            ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=g.device)
-            N.check(lib.ldm_colsum(g.data_ptr(), N.dtype_code(dt), T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
-                                   N.stream()), "ldm_colsum")
+        grads_w, grads_b = _weight_bias_grads(pack, g, h, F, T, F, g.device, dt)
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
-        return (dag, dres, None, dw[:n], db[:n])
+        return (dag, None, dres, None, grads_w[0], grads_b[0])
 
 
-def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None) -> Tensor:
-    """w3(a * silu(g)) (+ residual) for the fused activation ag = [a | g]; one weight in ``pack``."""
+def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None, h: Tensor | None = None) -> Tensor:
+    """w3(a * silu(g)) (+ residual) for the fused activation ag = [a | g]; one weight in ``pack``.
+    ``h``: a * silu(g) if the caller has it (the second output of swiglu_up)."""
     assert len(pack.weights) == 1
-    return _SwiGLUDown.apply(ag, residual, pack, pack.weights[0], pack.biases[0])
+    return _SwiGLUDown.apply(ag, h, residual, pack, pack.weights[0], pack.biases[0])
 
 
 # ----------------------------------------------------------------------------
@@ -630,8 +719,9 @@ class _RopeAttention(torch.autograd.Function):
             q2 = q2.contiguous()
         # the rotation is applied in place; the pre-rotation values are not needed again
         # (the projection's backward uses only its own input and weights)
-        N.check(lib.ldm_rope_qk(q2.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
-                                1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
+        with _Timed("rope", 2.0 * B * S * 2 * D * q2.element_size()):
+            N.check(lib.ldm_rope_qk(q2.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
+                                    1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
         o = torch.empty(B * S, D, dtype=dt, device=qkv.device)
         saved = torch.empty(lib.ldm_attn_saved_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
         if dropout_p > 0.0:
@@ -642,8 +732,9 @@ class _RopeAttention(torch.autograd.Function):
                                              saved.data_ptr(), N.ptr(ws), float(dropout_p), int(seed), N.stream()),
                     "ldm_attn_fwd_dropout")
         else:
-            N.check(lib.ldm_attn_fwd(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
-                                     saved.data_ptr(), N.stream()), "ldm_attn_fwd")
+            with _Timed("attn.fwd", 4.0 * B * H * S * S * hd):
+                N.check(lib.ldm_attn_fwd(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
+                                         saved.data_ptr(), N.stream()), "ldm_attn_fwd")
         ctx.save_for_backward(q2, o, saved, cos, sin)
         ctx.key_valid = key_valid
         ctx.dropout = (float(dropout_p), int(seed))
@@ -678,9 +769,10 @@ class _RopeAttention(torch.autograd.Function):
         # attention backward with the rotary backward fused into its stores where the kernel has it
         rc = -3
         if FUSED_UNROPE and dt == torch.bfloat16:
-            rc = lib.ldm_attn_bwd_unrope(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
-                                         g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
-                                         cos.data_ptr(), sin.data_ptr(), 1.0 / math.sqrt(hd), N.stream())
+            with _Timed("attn.bwd", 10.0 * B * H * S * S * hd):
+                rc = lib.ldm_attn_bwd_unrope(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                             g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
+                                             cos.data_ptr(), sin.data_ptr(), 1.0 / math.sqrt(hd), N.stream())
             if rc not in (-2, -3):
                 N.check(rc, "ldm_attn_bwd_unrope")
         if rc in (-2, -3):
@@ -704,7 +796,7 @@ def rope_attention(qkv: Tensor, key_valid: Tensor | None, B: int, S: int, H: int
 # ----------------------------------------------------------------------------
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode):
+    def forward(ctx, logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode, link):
         N.require_device(logits)
         lib = N.lib()
         V = logits.shape[-1]
@@ -727,7 +819,12 @@ class _MaskedCE(torch.autograd.Function):
                                int(mask_token_id), N.ptr(mb), N.ptr(av), N.ptr(sw), norm_mode, lse.data_ptr(),
                                tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), N.stream()), "ldm_ce_fwd")
         ctx.compact = None
-        if (l2.data_ptr() in _COMPACT_OK and l2.dtype == torch.bfloat16 and T > 1 and ld % PAD_N == 0
+        # the logits came straight from the vocabulary projection (same buffer, same row stride) and its
+        # backward can take compact rows
+        if link is not None and not (link.y_ptr == l2.data_ptr() and link.ld == ld):
+            link = None
+        ctx.link = link
+        if (link is not None and link.compact_ok and l2.dtype == torch.bfloat16 and T > 1 and ld % PAD_N == 0
                 and ld == _round_up(V, PAD_N)):
             rows = torch.empty(T, dtype=torch.int32, device=dev)
             cnt = torch.empty(1, dtype=torch.int32, device=dev)
@@ -746,7 +843,8 @@ class _MaskedCE(torch.autograd.Function):
         T, V = l2.shape
         Vp = _round_up(V, PAD_N)
         g = gout.reshape(1).float().contiguous()
-        if ctx.compact is not None and l2.data_ptr() in _COMPACT_OK:
+        link = ctx.link
+        if ctx.compact is not None:
             rows, cnt = ctx.compact
             dlc = torch.empty(_round_up(T, 64), Vp, dtype=l2.dtype, device=l2.device)
             N.check(lib.ldm_ce_bwd_compact(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(),
@@ -754,9 +852,8 @@ class _MaskedCE(torch.autograd.Function):
                                            rows.data_ptr(), cnt.data_ptr(), dlc.data_ptr(), Vp, N.stream()),
                     "ldm_ce_bwd_compact")
             dummy = torch.zeros(1, dtype=l2.dtype, device=l2.device)
-            _COMPACT_GRAD.clear()
-            _COMPACT_GRAD[l2.data_ptr()] = (dlc, rows, cnt, dummy)
-            return dummy.expand(tuple(shape)), None, None, None, None, None, None, None
+            link.grad = (dlc, rows, cnt, dummy)
+            return dummy.expand(tuple(shape)), None, None, None, None, None, None, None, None
         dl = torch.empty(T, Vp, dtype=l2.dtype, device=l2.device)
         N.check(lib.ldm_ce_bwd(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(), N.ptr(mi),
                                mask_token_id, N.ptr(mb), N.ptr(av), N.ptr(sw), norm_mode, lse.data_ptr(),
@@ -766,10 +863,9 @@ class _MaskedCE(torch.autograd.Function):
             dl, tuple(shape), _padded_strides(shape, Vp))
         if d.dtype != in_dtype:
             d = d.to(in_dtype)
-        else:
-            _ZERO_PADDED.clear()
-            _ZERO_PADDED[dl.data_ptr()] = Vp
-        return d, None, None, None, None, None, None, None
+        elif link is not None:
+            link.zero_padded = (dl.data_ptr(), Vp)
+        return d, None, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------
@@ -800,7 +896,8 @@ class _HeadMaskedCE(torch.autograd.Function):
     the dense computation's: the skipped rows contribute exact zeros there."""
 
     @staticmethod
-    def forward(ctx, x2, pack: PackedWeights, targets, masked_ids, att_valid, mask_token_id, want_grad, *params):
+    def forward(ctx, x2, pack: PackedWeights, targets, masked_ids, att_valid, mask_token_id, want_grad, seq_weight,
+                seq, norm_mode, *params):
         N.require_device(x2)
         lib = N.lib()
         st = N.stream()
@@ -819,33 +916,36 @@ class _HeadMaskedCE(torch.autograd.Function):
         xc = torch.empty(Tp, k, dtype=torch.bfloat16, device=dev)
         N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), cnt.data_ptr(), T, k,
                                     xc.data_ptr(), st), "ldm_gather_rows")
-        tgc = tg[rows.long()]                                       # entries past the count repeat row 0: unused
+        rows_l = rows.long()
+        tgc = tg[rows_l]                                            # entries past the count repeat row 0: unused
+        # weight of compact row i = weight of the sequence its source row belongs to (1/t in the paper form)
+        wc = None
+        if seq_weight is not None:
+            wc = seq_weight.reshape(-1).float()[rows_l // int(seq)].contiguous()
+        norm_T = float(T)
         lc = torch.empty(Tp, n_pad, dtype=torch.bfloat16, device=dev)
-        ev = GEMM_EVENTS.get("head.fwd") if GEMM_EVENTS is not None else None
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        N.check(lib.ldm_gemm_rows_dyn(N.BF16, 1, T, n_pad, k, xc.data_ptr(), k, w.data_ptr(), k, lc.data_ptr(), n_pad,
-                                      b.data_ptr(), cnt.data_ptr(), None, st), "ldm_gemm_rows_dyn")
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1, 2.0 * n_pad * k, cnt))              # flops per row; rows = cnt (device)
+        with _Timed("gemm.fwd", 2.0 * n_pad * k, cnt):              # flops per row; rows = cnt (device)
+            N.check(lib.ldm_gemm_rows_dyn(N.BF16, 1, T, n_pad, k, xc.data_ptr(), k, w.data_ptr(), k, lc.data_ptr(), n_pad,
+                                          b.data_ptr(), cnt.data_ptr(), None, st), "ldm_gemm_rows_dyn")
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         tmp = torch.empty(T, dtype=torch.float32, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)
         ctx.grad_ready = bool(want_grad and FUSED_CE_GRAD and pack.n <= 131072)
         if ctx.grad_ready:
             # one read + one write of the compact logits: they leave this call as d(loss)/d(logits)
-            N.check(lib.ldm_ce_fwd_grad(lc.data_ptr(), N.BF16, n_pad, Tp, pack.n, tgc.data_ptr(), cnt.data_ptr(), 0, 0.0,
-                                        lse.data_ptr(), tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), st),
-                    "ldm_ce_fwd_grad")
+            with _Timed("ce", 4.0 * n_pad, cnt):                    # bytes per row: read + write, bf16
+                N.check(lib.ldm_ce_fwd_grad(lc.data_ptr(), N.BF16, n_pad, Tp, pack.n, tgc.data_ptr(), cnt.data_ptr(),
+                                            int(norm_mode), norm_T, N.ptr(wc), lse.data_ptr(), tmp.data_ptr(),
+                                            out[0:1].data_ptr(), out[1:2].data_ptr(), st), "ldm_ce_fwd_grad")
         else:
             valid = torch.arange(T, dtype=torch.int32, device=dev) < cnt  # compact row i exists
             N.check(lib.ldm_ce_fwd(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
-                                   valid.view(torch.uint8).data_ptr(), None, None, 0, lse.data_ptr(), tmp.data_ptr(),
-                                   out[0:1].data_ptr(), out[1:2].data_ptr(), st), "ldm_ce_fwd")
+                                   valid.view(torch.uint8).data_ptr(), None, N.ptr(wc), int(norm_mode), lse.data_ptr(),
+                                   tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), st), "ldm_ce_fwd")
         ctx.pack = pack
         ctx.save_for_backward(xc, w, lc, tgc, lse, out, rows, cnt)
+        ctx.wc = wc
+        ctx.norm_mode = int(norm_mode)
         ctx.dims = (T, k)
         ctx.done = False
         FUSED_HEAD_STATS["used"] += 1
@@ -872,19 +972,22 @@ class _HeadMaskedCE(torch.autograd.Function):
         else:
             ident = torch.arange(T, dtype=torch.int32, device=dev)
             # dlogits over the logits, in place (each element is read and written by the same thread)
-            N.check(lib.ldm_ce_bwd_compact(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), None, 0,
-                                           lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(), ident.data_ptr(),
-                                           cnt.data_ptr(), lc.data_ptr(), n_pad, st), "ldm_ce_bwd_compact")
+            N.check(lib.ldm_ce_bwd_compact(lc.data_ptr(), N.BF16, n_pad, T, pack.n, 1, tgc.data_ptr(), N.ptr(ctx.wc),
+                                           ctx.norm_mode, lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(),
+                                           ident.data_ptr(), cnt.data_ptr(), lc.data_ptr(), n_pad, st),
+                    "ldm_ce_bwd_compact")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
-            N.check(lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, lc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(),
-                                          k, None, cnt.data_ptr(), rows.data_ptr(), st), "ldm_gemm_rows_dyn")
+            with _Timed("gemm.dx", 2.0 * k * n_pad, cnt):
+                N.check(lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, lc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(),
+                                              k, None, cnt.data_ptr(), rows.data_ptr(), st), "ldm_gemm_rows_dyn")
         dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
         dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
-        N.check(lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, _round_up(T, 64), lc.data_ptr(), n_pad, xc.data_ptr(), k,
-                                      dw.data_ptr(), k, cnt.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None,
-                                      st), "ldm_gemm_acc_kdyn")
+        with _Timed("gemm.dw", 2.0 * n_pad * k, cnt):
+            N.check(lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, _round_up(T, 64), lc.data_ptr(), n_pad, xc.data_ptr(), k,
+                                          dw.data_ptr(), k, cnt.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None,
+                                          st), "ldm_gemm_acc_kdyn")
         if not FUSED_BIAS_GRAD:
             ws = torch.empty(lib.ldm_colsum_ws_floats(T, n_pad), dtype=torch.float32, device=dev)
             N.check(lib.ldm_colsum_rows_dyn(lc.data_ptr(), N.BF16, T, n_pad, n_pad, db.data_ptr(), ws.data_ptr(),
@@ -895,16 +998,19 @@ class _HeadMaskedCE(torch.autograd.Function):
             grads_w.append(dw[off:off + ne])
             grads_b.append(db[off:off + ne])
             off += ne
-        return (dx, None, None, None, None, None, None, *grads_w, *grads_b)
+        return (dx, None, None, None, None, None, None, None, None, None, *grads_w, *grads_b)
 
 
 def head_masked_ce(x: Tensor, pack: PackedWeights, targets: Tensor, masked_ids: Tensor, mask_token_id: int,
-                   att_valid: Tensor | None = None) -> Tensor:
-    """variational_lower_bound_loss(linear(x), ...) computed on the participating rows only."""
+                   att_valid: Tensor | None = None, seq_weight: Tensor | None = None, seq: int = 1,
+                   norm_mode: int = 0) -> Tensor:
+    """variational_lower_bound_loss(linear(x), ...) computed on the participating rows only.
+    ``seq_weight`` [B] (rows of sequence b weigh seq_weight[b]; ``seq`` = rows per sequence) and
+    ``norm_mode`` (0: number of participating rows, 1: all rows) are the paper-form extensions."""
     x2 = _rows2d(x)
     want_grad = torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in pack.weights + pack.biases))
-    return _HeadMaskedCE.apply(x2, pack, targets, masked_ids, att_valid, mask_token_id, want_grad, *pack.weights,
-                               *pack.biases)
+    return _HeadMaskedCE.apply(x2, pack, targets, masked_ids, att_valid, mask_token_id, want_grad, seq_weight,
+                               int(seq), int(norm_mode), *pack.weights, *pack.biases)
 
 
 def _padded_strides(shape, ld):
@@ -918,4 +1024,6 @@ def _padded_strides(shape, ld):
 
 def masked_ce(logits, targets, *, masked_ids=None, mask_token_id=0, mask_bool=None, att_valid=None,
               seq_weight=None, norm_mode=0) -> Tensor:
-    return _MaskedCE.apply(logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode)
+    link = getattr(logits, "_ldm_head_link", None) if torch.is_grad_enabled() else None
+    return _MaskedCE.apply(logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode,
+                           link)

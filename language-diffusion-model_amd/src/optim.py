@@ -42,7 +42,15 @@ class FusedAdamW(torch.optim.Optimizer):
         module = getattr(self, "_module", None)
         if module is None:
             return
-        packs = [pk for m in module.modules() for pk in getattr(m, "_packs", {}).values()]
+        # only the packs of each module's CURRENT compute dtype are refreshed by the update kernel; a
+        # module that was switched (bf16 training, then an fp32 evaluation) also holds packs of the other
+        # dtype: those are marked stale after every step and re-cast when they are next used
+        packs, stale = [], []
+        for m in module.modules():
+            cur = getattr(m, "compute_dtype", None)
+            for pk in getattr(m, "_packs", {}).values():
+                (packs if (cur is None or pk.dtype == cur) else stale).append(pk)
+        self._stale_packs = stale
         sig = tuple((id(pk), id(pk.w)) for pk in packs)
         if sig == self._shadow_sig:
             return
@@ -91,8 +99,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["step"] += 1
                 k = int(st["step"].item())
                 sh = self._shadows.get(id(p), [])
-                if len(sh) > 1:        # a parameter packed more than once: the extra copies are re-cast lazily
-                    raise RuntimeError("a parameter belongs to more than one weight pack of one dtype")
+                if len(sh) > 1:
+                    raise RuntimeError("a parameter belongs to more than one weight pack of its module's compute dtype")
                 entries.append((k, p, g, st["exp_avg"], st["exp_avg_sq"], sh[0] if sh else None))
             # tensors of one launch share the step count (bias correction); group by it
             by_step: dict = {}
@@ -113,4 +121,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 N.check(lib.ldm_adamw_step(arr, len(es), step_no, float(group["lr"]), float(b1), float(b2),
                                            float(group["eps"]), float(group["weight_decay"]), float(self.grad_scale),
                                            N.stream()), "ldm_adamw_step")
+        for pk in getattr(self, "_stale_packs", ()):
+            pk._key = None
         return loss

@@ -14,6 +14,7 @@ import gc
 
 import torch
 
+from . import ops
 from .loss import variational_lower_bound_loss
 
 
@@ -30,15 +31,16 @@ class DiffusionLanguageModelTrainer:
         self._loss_event = None
         self._staged = None
         self._gc_frozen = False
-        # an optimizer that neither refreshes the packed compute-dtype weight copies itself
-        # (src.optim.FusedAdamW attached to the model) nor is known to move the parameters' version
-        # counters: mark the copies stale after every step
+        self.objective = "reference"  # "paper": per-sequence t ~ U(eps,1), 1/t weights, B*L normaliser (not the reference's)
+        self.objective_eps = 1e-3
+        # Does the optimizer keep the packed compute-dtype weight copies current by itself?  Only
+        # src.optim.FusedAdamW attached to the model does.  Anything else -- torch optimizers (the fused
+        # ones update parameters without moving their version counters), wrappers such as accelerate's
+        # AcceleratedOptimizer (a torch Optimizer subclass that never runs Optimizer.__init__, so it has
+        # no hook registry and fires no hooks) -- gets the copies marked stale right after its step().
         from .optim import FusedAdamW
-        if (isinstance(optimizer, torch.optim.Optimizer) and not getattr(optimizer, "_ldm_epoch_hook", False)
-                and not (isinstance(optimizer, FusedAdamW) and getattr(optimizer, "_module", None) is not None)):
-            from . import ops
-            optimizer.register_step_post_hook(lambda *_a, **_k: ops.parameters_changed())
-            optimizer._ldm_epoch_hook = True
+        inner = getattr(optimizer, "optimizer", optimizer)    # accelerate keeps the real one here
+        self._marks_stale = not (isinstance(inner, FusedAdamW) and getattr(inner, "_module", None) is not None)
 
     def _step(self, batch) -> torch.Tensor:
         input_ids = batch["input_ids"]
@@ -47,7 +49,11 @@ class DiffusionLanguageModelTrainer:
         if self.fused_head_loss and hasattr(self.model, "training_loss"):
             # same value and gradients as the two calls below; the logits of positions the loss
             # never reads are not formed
-            loss = self.model.training_loss(input_ids=input_ids, attention_mask=attention_mask)
+            if self.objective == "reference":
+                loss = self.model.training_loss(input_ids=input_ids, attention_mask=attention_mask)
+            else:
+                loss = self.model.training_loss(input_ids=input_ids, attention_mask=attention_mask,
+                                                objective=self.objective, eps=self.objective_eps)
         else:
             logits, masked_input_ids, _ = self.model(input_ids=input_ids, attention_mask=attention_mask)
             loss = variational_lower_bound_loss(logits=logits, targets=input_ids,
@@ -56,6 +62,8 @@ class DiffusionLanguageModelTrainer:
         self._stage_loss(loss)
         self.accelerator.backward(loss)
         self.optimizer.step()
+        if self._marks_stale:
+            ops.parameters_changed()
         self.global_step += 1
         if not self._gc_frozen:
             # after the first step everything long-lived exists: park it in the collector's permanent

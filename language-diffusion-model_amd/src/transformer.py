@@ -86,14 +86,13 @@ class SwiGLU(nn.Module):
             if which == "in":
                 self._packs[key] = ops.PackedWeights([self.w1.weight, self.w2.weight],
                                                      [self.w1.bias, self.w2.bias], self.compute_dtype, "w12")
-                self._packs[key].swiglu_in = True   # its GEMM may also emit a * silu(g)
             else:
                 self._packs[key] = ops.PackedWeights([self.w3.weight], [self.w3.bias], self.compute_dtype, "w3")
         return self._packs[key]
 
     def forward(self, x: Tensor, residual: Tensor | None = None) -> Tensor:
-        ag = ops.packed_linear(x, self._pack("in"))
-        return ops.swiglu_down(ag, self._pack("out"), residual=residual)
+        ag, h = ops.swiglu_up(x, self._pack("in"))      # h = a * silu(g) out of the same GEMM's epilogue
+        return ops.swiglu_down(ag, self._pack("out"), residual=residual, h=h)
 
 
 def rotate_half(x: Tensor) -> Tensor:
@@ -302,21 +301,28 @@ class DiffusionTransformer(nn.Module):
         return ops.packed_linear(self.hidden_states(input_ids, attention_mask), self._head_pack())
 
     def masked_token_loss(self, masked_input_ids: Tensor, targets: Tensor, mask_token_id: int,
-                          attention_mask: Tensor | None = None) -> Tensor:
+                          attention_mask: Tensor | None = None, *, seq_weight: Tensor | None = None,
+                          normalize_by: str = "masked") -> Tensor:
         """variational_lower_bound_loss(self(masked_input_ids, attention_mask), targets, ...)
         (src/loss.py:31-65 on src/transformer.py:413-444) without the logits of positions the
         loss does not read; falls back to exactly that composition when the fused kernels do
-        not take the problem."""
+        not take the problem.  ``seq_weight`` / ``normalize_by``: the keyword-only extensions of
+        variational_lower_bound_loss (per-sequence weight, "masked" or "tokens" normaliser)."""
         from .loss import variational_lower_bound_loss
+        if normalize_by not in ("masked", "tokens"):
+            raise ValueError(f"normalize_by must be 'masked' or 'tokens', got {normalize_by!r}")
         x = self.hidden_states(masked_input_ids, attention_mask)
         pack = self._head_pack()
         x2 = x.reshape(-1, x.shape[-1])
         if ops.head_loss_eligible(x2, pack):
             att_valid = (attention_mask == 1) if attention_mask is not None else None
-            return ops.head_masked_ce(x2, pack, targets, masked_input_ids, mask_token_id, att_valid)
+            return ops.head_masked_ce(x2, pack, targets, masked_input_ids, mask_token_id, att_valid,
+                                      seq_weight=seq_weight, seq=masked_input_ids.shape[-1],
+                                      norm_mode=0 if normalize_by == "masked" else 1)
         logits = ops.packed_linear(x, pack)
         return variational_lower_bound_loss(logits=logits, targets=targets, masked_input_ids=masked_input_ids,
-                                            mask_token_id=mask_token_id, attention_mask=attention_mask)
+                                            mask_token_id=mask_token_id, attention_mask=attention_mask,
+                                            seq_weight=seq_weight, normalize_by=normalize_by)
 
 
 __all__ = ["DiffusionTransformerConfig", "RMSNorm", "SwiGLU", "rotate_half", "RotaryPositionEmbedding",

@@ -161,11 +161,32 @@ def vlb_loss(logits, targets, masked_input_ids, mask_token_id=MASK, attention_ma
     return masked_ce(logits, targets, m)
 
 
+def vlb_loss_paper(logits, targets, masked_input_ids, t_seq, mask_token_id=MASK, attention_mask=None):
+    """The LLaDA-paper form of the objective -- NOT in the reference (its loss is src/loss.py:20-22:
+    unweighted mean over the masked positions): with t_b the masking ratio of sequence b,
+
+        loss = (1 / (B * L)) * sum_b (1 / t_b) * sum_{i in masked(b)} CE(logits[b, i], targets[b, i])
+
+    over the same re-derived mask as ``vlb_loss``.  An empty mask gives 0.  This restates the
+    formula the HIP kernels implement for ``objective="paper"``; there is no reference output to
+    pin it against (parity unpinned w.r.t. the reference)."""
+    m = masked_input_ids == mask_token_id
+    if attention_mask is not None:
+        m = m & (attention_mask == 1)
+    bsz, seq = masked_input_ids.shape
+    v = logits.shape[-1]
+    ce = F.cross_entropy(logits.reshape(-1, v).float(), targets.reshape(-1), reduction="none").reshape(bsz, seq)
+    w = (1.0 / t_seq.to(torch.float32)).reshape(bsz, 1)
+    return (ce * w * m.to(ce.dtype)).sum() / float(bsz * seq)
+
+
 # --------------------------------------------------------------------------
 # one step (forward + loss + backward), src/trainer.py:119-137
 # --------------------------------------------------------------------------
-def step_loss_and_grads(params, cfg, input_ids, attention_mask, t, draw, autocast_bf16=False):
+def step_loss_and_grads(params, cfg, input_ids, attention_mask, t, draw, autocast_bf16=False, objective="reference"):
     """Returns (loss, grads dict, masked ids, mask, logits) for one step.
+
+    ``objective="paper"``: ``t`` is a per-sequence fp32 tensor [B] and the loss is ``vlb_loss_paper``.
 
     ``params`` is a dict name -> fp32 tensor (no grad required on entry).
     With ``autocast_bf16`` the forward+loss run under
@@ -182,7 +203,10 @@ def step_loss_and_grads(params, cfg, input_ids, attention_mask, t, draw, autocas
         logits = logits.float()
     else:
         logits = transformer_forward(leaf, cfg, masked, attention_mask)
-    loss = vlb_loss(logits, input_ids, masked, MASK, attention_mask)
+    if objective == "paper":
+        loss = vlb_loss_paper(logits, input_ids, masked, t, MASK, attention_mask)
+    else:
+        loss = vlb_loss(logits, input_ids, masked, MASK, attention_mask)
     grads = {}
     if loss.grad_fn is not None:
         loss.backward()

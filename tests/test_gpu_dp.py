@@ -1,7 +1,14 @@
-"""The multi-rank training path on ONE GPU: two ranks (gloo, host-staged buckets) run trainer steps
-with FusedAdamW taking over the 1 / world_size scaling.  With the same batch and seeds on both
-ranks the mean gradient equals the single-process gradient, so the parameters after three steps
-must equal a single-process run."""
+"""The multi-rank training path on ONE GPU (a one-GPU box cannot run two RCCL ranks, so the two
+ranks talk over gloo with host-staged buckets; everything else -- bucket assignment, hooks, launch
+order, 1/W scaling -- is the code the RCCL path runs).
+
+* same batch on both ranks + FusedAdamW taking over the 1 / world_size scaling: the parameters after
+  three steps must equal a single-process run;
+* DIFFERENT batches per rank: every rank's gradients after backward must equal the oracle's mean of
+  the per-rank gradients (each rank's loss normalised by its own masked count -- what DDP computes
+  for the reference, main.py:105-108 + src/trainer.py:136), dense head in fp32 and fused head in bf16;
+* `python bench.py --gpus 2` typed as a plain command starts its own two ranks and reports
+  ranks_seen = 2."""
 import os
 import sys
 
@@ -83,3 +90,136 @@ def test_two_ranks_fused_adamw_equal_single_process(dev):
         for n, v in ref_params.items():
             err = np.linalg.norm(res[r][1][n] - v) / max(np.linalg.norm(v), 1e-30)
             assert err < 1e-4, (r, n, err)
+
+
+# --------------------------------------------------------------------------- different data per rank
+class _InjectedDraw:
+    def __init__(self, inner, draw):
+        self.inner, self.draw = inner, draw
+
+    def apply_random_mask(self, input_ids, mask_prob):
+        return self.inner.apply_random_mask(input_ids, mask_prob, draw=self.draw)
+
+
+def _dp_case(kind):
+    """(oracle config, batch, seq, dtype, fused head?) of the two different-data cases."""
+    from oracle import step_oracle as so
+    if kind == "tiny_fp32_dense":
+        return so.OracleConfig(vocab_size=500, d_model=64, nhead=2, num_layers=2, dim_feedforward=128), 3, 32, torch.float32, False
+    # default width, one layer, T = 1024 rows per rank: the bf16 fused LM-head loss takes this shape
+    return so.OracleConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=1, dim_feedforward=1024), 2, 512, torch.bfloat16, True
+
+
+def _rank_inputs(kind, rank):
+    from oracle import step_oracle as so
+    ocfg, B, S, _, _ = _dp_case(kind)
+    ids, att = so.synthetic_batch(B, S, ocfg.vocab_size, seed=100 + rank, ragged=True, dirty=(rank == 1))
+    draw = torch.rand(B, S, generator=torch.Generator().manual_seed(200 + rank))
+    return ids, att, draw, 0.35 + 0.3 * rank       # a different t per rank as well
+
+
+def _grad_worker(rank, world, port, kind, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import types
+    import torch.distributed as dist
+    from oracle import step_oracle as so
+    from src import ops
+    from src.dp import GradBucketDataParallel, HipAccelerator
+    from src.loss import variational_lower_bound_loss
+    from src.masking_strategy import create_masking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ocfg, B, S, dtype, fused = _dp_case(kind)
+    params = so.init_params(ocfg, seed=11)
+    tr = DiffusionTransformer(DiffusionTransformerConfig(
+        vocab_size=ocfg.vocab_size, d_model=ocfg.d_model, nhead=ocfg.nhead, num_layers=ocfg.num_layers,
+        dim_feedforward=ocfg.dim_feedforward, dropout=0.0, layer_norm_eps=1e-12, max_position_embeddings=512))
+    tr.load_state_dict(params, strict=False)
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
+    acc = HipAccelerator(mixed_precision="bf16" if dtype == torch.bfloat16 else "no", device=dev,
+                         bucket_bytes=(64 << 10) if ocfg.d_model == 64 else (32 << 20))
+    model = acc.prepare(model)
+    assert isinstance(model, GradBucketDataParallel) and model.num_buckets >= 2 and not model.defer_scale
+    ids, att, draw, t = _rank_inputs(kind, rank)
+    ids, att = ids.to(dev), att.to(dev)
+    model.module.masking_strategy = _InjectedDraw(model.module.masking_strategy, draw.to(dev))
+    model.train()
+    used0 = ops.FUSED_HEAD_STATS["used"]
+    if fused:
+        loss = model.module.training_loss(ids, att, t=torch.tensor([t]))
+    else:
+        logits, masked, _ = model(input_ids=ids, attention_mask=att, t=torch.tensor([t]))
+        loss = variational_lower_bound_loss(logits, ids, masked, 103, att)
+    assert (ops.FUSED_HEAD_STATS["used"] == used0 + 1) == fused
+    acc.backward(loss)
+    torch.cuda.synchronize()
+    # numpy, not tensors: a tensor in a Queue is handed over by file descriptor and the sender may be gone
+    grads = {n: p.grad.detach().float().cpu().numpy() for n, p in model.module.transformer.named_parameters()}
+    q.put((rank, float(loss.item()), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["tiny_fp32_dense", "default_width_bf16_fused"])
+def test_two_ranks_different_data_equal_oracle_mean(dev, kind):
+    from conftest import rel_err
+    from oracle import step_oracle as so
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1500) + (7 if kind.startswith("tiny") else 0)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    # the oracle runs while the ranks do: per-rank loss and gradients, then their mean
+    ocfg, B, S, dtype, _ = _dp_case(kind)
+    params = so.init_params(ocfg, seed=11)
+    per_rank = []
+    for r in range(2):
+        ids, att, draw, t = _rank_inputs(kind, r)
+        ol, og, _, _, _ = so.step_loss_and_grads(params, ocfg, ids, att, t, draw)
+        per_rank.append((float(ol), og))
+    mean = {n: (per_rank[0][1][n] + per_rank[1][1][n]) / 2 for n in per_rank[0][1]}
+    res = {}
+    for _ in range(2):
+        rank, loss, grads = q.get(timeout=300)
+        res[rank] = (loss, {n: torch.from_numpy(v) for n, v in grads.items()})
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for r in range(2):
+        assert abs(res[r][0] - per_rank[r][0]) <= tol * abs(per_rank[r][0])     # each rank's OWN loss
+        names = [n for n in mean if not n.endswith("k_proj.bias")]
+        mine = torch.cat([res[r][1][n].flatten() for n in names])
+        want = torch.cat([mean[n].flatten() for n in names])
+        assert rel_err(mine, want) < tol, (r, "whole gradient")
+        for n in names:
+            assert rel_err(res[r][1][n], mean[n]) < tol, (r, n)
+    # and both ranks hold the same reduced gradient
+    for n in mean:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_bench_starts_its_own_ranks(dev):
+    """`python bench.py --gpus 2 ...` with no launcher: one JSON line, n_gpus 2, ranks_seen 2."""
+    import json
+    import subprocess
+    env = dict(os.environ, LDM_DP_BACKEND="gloo", LDM_DP_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["grad_buckets"] >= 2
+    assert rec["config"]["global_batch"] == 32 and rec["value"] > 0
+    # a child that fails makes the command fail
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--config",
+                          "nonexistent"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0

@@ -540,9 +540,10 @@ def test_gemm_rows_dyn_many_tiles(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("rows,V,count", [(128, 30522, 100), (64, 2051, 64), (256, 32000, 0), (64, 40000, 37),
                                           (64, 126464, 3)])
-def test_ce_fwd_grad_one_pass(dev, dtype, rows, V, count):
+def test_ce_fwd_grad_one_pass(dev, dtype, rows, V, count, weighted):
     """ldm_ce_fwd_grad (loss and gradient from one read of each compact row) against
     F.cross_entropy + autograd on the same rows (src/loss.py:22), incl. a vocabulary that is not a
     multiple of 8, zero participating rows, the zeroed rounding rows, and the 1024-thread form."""
@@ -560,14 +561,20 @@ def test_ce_fwd_grad_one_pass(dev, dtype, rows, V, count):
     tmp = torch.empty(rows, device=dev)
     out = torch.full((2,), -1.0, device=dev)
     sentinel = x[(count + 63) // 64 * 64:].clone()
-    N.check(lib.ldm_ce_fwd_grad(x.data_ptr(), N.dtype_code(dtype), ld, rows, V, tg.data_ptr(), cnt.data_ptr(), 0, 0.0,
-                                lse.data_ptr(), tmp.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), N.stream()),
-            "ldm_ce_fwd_grad")
+    # weighted: per-row weights and the fixed normaliser of the paper-form objective (sum_i w_i CE_i / norm_T)
+    wr = (0.5 + 4 * torch.rand(rows, device=dev)) if weighted else None
+    norm_mode, norm_T = (1, 777.0) if weighted else (0, 0.0)
+    N.check(lib.ldm_ce_fwd_grad(x.data_ptr(), N.dtype_code(dtype), ld, rows, V, tg.data_ptr(), cnt.data_ptr(), norm_mode,
+                                norm_T, N.ptr(wr), lse.data_ptr(), tmp.data_ptr(), out[0:1].data_ptr(),
+                                out[1:2].data_ptr(), N.stream()), "ldm_ce_fwd_grad")
     assert float(out[1]) == count
     if count == 0:
         assert float(out[0]) == 0.0
     else:
-        loss = F.cross_entropy(ref_in, tg[:count])
+        if weighted:
+            loss = (F.cross_entropy(ref_in, tg[:count], reduction="none") * wr[:count]).sum() / norm_T
+        else:
+            loss = F.cross_entropy(ref_in, tg[:count])
         loss.backward()
         assert abs(float(out[0]) - float(loss)) <= 1e-5 * abs(float(loss))
         tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
@@ -703,7 +710,6 @@ def test_swiglu_module_fused_up_projection_matches_two_pass(dev):
         finally:
             ops.FUSED_SWIGLU_UP = True
         out[fused] = (y.detach().float(), xx.grad.float(), {n: p.grad.clone() for n, p in m.named_parameters()})
-    assert not ops._SWIGLU_H
     assert rel_err(out[True][0], out[False][0]) < 6e-3
     assert rel_err(out[True][1], out[False][1]) < 6e-3
     for n in out[True][2]:

@@ -92,12 +92,87 @@ def test_weight_copy_epoch_and_loss_value_host_logic():
         pass
     opt = _Opt(lin.parameters(), lr=0.1)
     tr = DiffusionLanguageModelTrainer(lin, opt, None, None)
-    assert getattr(opt, "_ldm_epoch_hook", False)  # the trainer marks copies stale after every step
-    e0 = ops.WEIGHTS_EPOCH
-    lin(torch.randn(2, 8)).sum().backward()
-    opt.step()
-    assert ops.WEIGHTS_EPOCH == e0 + 1
+    assert tr._marks_stale                         # the trainer marks copies stale after every step() it makes
     assert tr.loss_value(torch.tensor(1.5)) == 1.5
+
+
+def test_trainer_accepts_an_accelerate_prepared_optimizer():
+    """The reference's main.py hands the trainer what Accelerator.prepare returns.  accelerate's
+    AcceleratedOptimizer subclasses torch.optim.Optimizer without running its __init__ (no hook
+    registry, and its step() fires no hooks): the trainer must not register hooks on it and must
+    mark the packed weight copies stale itself after each step."""
+    import pytest
+    import torch
+    accelerate = pytest.importorskip("accelerate")
+    from src import ops
+    from src.trainer import DiffusionLanguageModelTrainer
+
+    class _Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(8, 4)
+            self.tokenizer = None
+
+        def training_loss(self, input_ids, attention_mask=None):
+            return self.lin(input_ids).pow(2).mean()
+
+    model = _Toy()
+    acc = accelerate.Accelerator(cpu=True)
+    opt = acc.prepare(torch.optim.AdamW(model.parameters(), lr=1e-2))
+    assert not hasattr(opt, "_optimizer_step_post_hooks")      # the situation this test is about
+    tr = DiffusionLanguageModelTrainer(model, opt, None, acc)
+    assert tr._marks_stale
+    w0 = model.lin.weight.detach().clone()
+    e0 = ops.WEIGHTS_EPOCH
+    loss = tr._step({"input_ids": torch.randn(3, 8)})
+    assert ops.WEIGHTS_EPOCH == e0 + 1
+    assert not torch.equal(w0, model.lin.weight.detach())
+    assert tr.loss_value(loss) == loss.item()
+    # the accelerator's own prepare() tolerates the same object
+    from src.dp import HipAccelerator
+    HipAccelerator(device="cpu").prepare(opt)
+
+
+def test_head_link_travels_with_the_tensor_not_with_addresses():
+    """The compact-gradient hand-over between the masked CE and the vocabulary projection is a
+    per-call object referenced by the logits tensor and by the projection's autograd node; nothing
+    process-global is keyed by device addresses."""
+    from src import ops
+    for name in ("_COMPACT_OK", "_COMPACT_GRAD", "_ZERO_PADDED", "_SWIGLU_H"):
+        assert not hasattr(ops, name)
+    a, b = ops._HeadLink(), ops._HeadLink()
+    a.grad = ("x",)
+    assert b.grad is None and b.zero_padded is None and not b.compact_ok
+
+
+def test_bench_launches_its_own_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts N ranks under
+    torch.distributed.run from a parent that has not imported torch, and returns their exit code."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    import pytest
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the parent's module-level imports do not pull in torch
+    src_text = open(bench.__file__).read()
+    head = src_text[:src_text.index("def main()")]
+    assert "\nimport torch" not in head
 
 
 def test_fused_adamw_refuses_host_tensors():
