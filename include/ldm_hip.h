@@ -79,6 +79,20 @@ int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd, const void
                     const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,
                     float *dw_partial, void *stream);
 
+/* ldm_rmsnorm_bwd for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the same kernels and results, but the dw partials live in a
+ * fixed 8 MiB device array inside the library instead of a caller-provided workspace, so the call
+ * needs no buffer beyond its inputs and outputs and allocates nothing.  No counterpart in the
+ * reference.  Limits: d <= ldm_rmsnorm_bwd_noalloc_max_d() (8192; larger returns LDM_E_WORKSPACE).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; stream-ordered calls are safe.  With d <= 1024 the result is bit-identical to
+ * ldm_rmsnorm_bwd; above that fewer workgroups share the array, so dw is summed in a different
+ * order (dx is identical). */
+int64_t ldm_rmsnorm_bwd_noalloc_max_d(void);
+int ldm_rmsnorm_bwd_noalloc(const void *x, const float *w, const float *rstd, const void *dy,
+                            const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,
+                            void *stream);
+
 /* ---------------------------------------------------------------- RoPE (+ query scale)
  * RotaryPositionEmbedding.apply_rotary_pos_emb + rotate_half + "q / sqrt(hd)"
  * (src/transformer.py:98-101,178-185,261).  Works in place on the q and k thirds of

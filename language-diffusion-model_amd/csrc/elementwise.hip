@@ -1,6 +1,7 @@
 // HBM-bound row kernels: embedding gather / scatter-add, RMSNorm fwd/bwd, RoPE,
 // SwiGLU, column sums, casts.  All move 8-16 B per lane per access.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -812,9 +813,9 @@ extern "C" int64_t ldm_rmsnorm_bwd_ws_floats(int64_t T, int64_t d) {
 template <typename T>
 static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, const void *dy,
                               const void *dres, int64_t rows, int64_t d, void *dx, float *dw,
-                              float *dw_partial, hipStream_t s) {
+                              float *dw_partial, hipStream_t s, int64_t max_blocks = kRmsBwdBlocks) {
   int64_t blocks = ceil_div(rows, 4);
-  if (blocks > kRmsBwdBlocks) blocks = kRmsBwdBlocks;
+  if (blocks > max_blocks) blocks = max_blocks;
   const unsigned grid = (unsigned)blocks;
   const size_t lds = (size_t)4 * d * sizeof(float);
   if (d % 8 == 0 && rms_nv8(d) <= 4) {
@@ -873,6 +874,62 @@ extern "C" int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd,
     return LDM_E_ALIGN;
   if (dtype == LDM_F32) return rmsnorm_bwd_launch<float>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s);
   if (dtype == LDM_BF16) return rmsnorm_bwd_launch<bf16_t>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s);
+  return LDM_E_DTYPE;
+}
+
+// ---------------------------------------------------------------- RMSNorm backward without a workspace argument
+// The per-workgroup dw partials live in a file-scope device array instead of a caller-provided
+// buffer, so the call neither allocates nor needs anything allocated for it.  Every GPU holds its
+// own copy of the array at its own address: the address is looked up once per device.
+constexpr int64_t kNoAllocScratchFloats = (int64_t)2 << 20;   // 8 MiB per GPU, held until the process ends
+static __device__ __align__(256) float scratch[kNoAllocScratchFloats];
+constexpr int kMaxDevices = 64;
+static float *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the CURRENT device (host code must never pass the array's name
+// to a kernel: on the host it is only a handle for this lookup)
+static int scratch_address(float **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return LDM_E_SHAPE;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    float *p = nullptr;
+    e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return LDM_E_WORKSPACE;
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return LDM_OK;
+}
+
+extern "C" int64_t ldm_rmsnorm_bwd_noalloc_max_d(void) { return 8192; }
+
+extern "C" int ldm_rmsnorm_bwd_noalloc(const void *x, const float *w, const float *rstd, const void *dy,
+                                       const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,
+                                       void *stream) {
+  if (T < 0 || d <= 0) return LDM_E_BADARG;
+  if (!dw) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 0) return (int)hipMemsetAsync(dw, 0, d * sizeof(float), s);
+  if (!x || !w || !rstd || !dy || !dx) return LDM_E_BADARG;
+  if (d % 4) return LDM_E_SHAPE;
+  if (d > ldm_rmsnorm_bwd_noalloc_max_d()) return LDM_E_WORKSPACE;   // the fixed scratch array is too small
+  if (!aligned_to(x, 16) || !aligned_to(dy, 16) || !aligned_to(dx, 16) || !aligned_to(w, 16) ||
+      (dres && !aligned_to(dres, 16)))
+    return LDM_E_ALIGN;
+  float *partial = nullptr;
+  const int rc = scratch_address(&partial);
+  if (rc) return rc;
+  // one row of d floats per workgroup: fewer workgroups than the workspace form when d > 1024.
+  // Every row the second stage reads is written by the first, so nothing needs clearing.
+  int64_t max_blocks = kNoAllocScratchFloats / d;
+  if (max_blocks > kRmsBwdBlocks) max_blocks = kRmsBwdBlocks;
+  if (dtype == LDM_F32) return rmsnorm_bwd_launch<float>(x, w, rstd, dy, dres, T, d, dx, dw, partial, s, max_blocks);
+  if (dtype == LDM_BF16) return rmsnorm_bwd_launch<bf16_t>(x, w, rstd, dy, dres, T, d, dx, dw, partial, s, max_blocks);
   return LDM_E_DTYPE;
 }
 

@@ -41,6 +41,8 @@ SIGNATURES = {
     "ldm_rmsnorm_fwd": (_i32, [_vp, _vp, _i64, _i64, _f32, _i32, _vp, _vp, _vp]),
     "ldm_rmsnorm_bwd_ws_floats": (_i64, [_i64, _i64]),
     "ldm_rmsnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ldm_rmsnorm_bwd_noalloc_max_d": (_i64, []),
+    "ldm_rmsnorm_bwd_noalloc": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "ldm_rope_qk": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _f32, _i32, _vp]),
     "ldm_swiglu_fwd": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "ldm_swiglu_bwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
