@@ -170,6 +170,20 @@ int ldm_gemm_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *x, int64_t 
                         int64_t ldw, const float *bias, void *ag, int64_t ld_ag, void *h, int64_t ld_h,
                         void *stream);
 
+/* The q/k/v projections, the rotary embedding and the query scale from ONE GEMM
+ * (src/transformer.py:242-244 then :255-261): qkv[T, 3D] = x Wqkv^T + bias with Wqkv = [Wq; Wk; Wv]
+ * ([3D, K], K contiguous), then, in the epilogue and in fp32, apply_rotary_pos_emb (rotate-half,
+ * :98-101,178-185) to every head of the q and k thirds -- the position of row r is r % seq -- and
+ * q *= q_scale: what ldm_gemm followed by ldm_rope_qk(inverse = 0) leaves, without the second pass
+ * (and without rounding q and k to bf16 before the rotation).  cos_t / sin_t: fp32 [seq, hd/2];
+ * step: fp32 [2, hd/2] = cos(16 theta_d) | sin(16 theta_d), theta_d = the angle per position of pair d
+ * (the epilogue walks down a wave's rows 16 positions at a time by angle addition, so that it needs the
+ * tables only once per tile).  BF16; T a multiple of 256, D of 256, hd in {32, 64, 96, 128},
+ * seq a multiple of 128 that divides T; otherwise LDM_E_SHAPE / LDM_E_ALIGN (use the two calls). */
+int ldm_gemm_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, int64_t seq, const void *x, int64_t ldx,
+                      const void *Wqkv, int64_t ldw, const float *bias, const float *cos_t, const float *sin_t,
+                      const float *step, float q_scale, void *qkv, int64_t ld_qkv, void *stream);
+
 /* Column sums (bias gradients): out[n] = sum_m X[m,n]; out fp32 [N], overwritten.
  * ws must hold ldm_colsum_ws_floats(M,N) floats. */
 int64_t ldm_colsum_ws_floats(int64_t M, int64_t N);

@@ -43,3 +43,6 @@ int ldm_gemm_mfma256_bf16_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void
 int ldm_gemm_mfma256_bf16_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W12,
                                      int64_t ldw, const float *bias, void *ag, int64_t ld_ag, void *h, int64_t ld_h,
                                      hipStream_t s);
+int ldm_gemm_mfma256_bf16_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, int64_t S, const void *x, int64_t ldx,
+                                   const void *W, int64_t ldw, const float *bias, const float *cos_t, const float *sin_t,
+                                   const float *step, float q_scale, void *qkv, int64_t ld_qkv, hipStream_t s);

@@ -109,7 +109,17 @@ extern "C" int ldm_gemm_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void *
   return ldm_gemm_mfma256_bf16_swiglu_fwd(T, F, K, x, ldx, W12, ldw, bias, ag, ld_ag, h, ld_h, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 13; }
+extern "C" int ldm_gemm_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, int64_t seq, const void *x, int64_t ldx,
+                                 const void *Wqkv, int64_t ldw, const float *bias, const float *cos_t,
+                                 const float *sin_t, const float *step, float q_scale, void *qkv, int64_t ld_qkv,
+                                 void *stream) {
+  if (T <= 0 || D <= 0 || K <= 0 || hd <= 0 || seq <= 0) return LDM_E_BADARG;
+  if (!x || !Wqkv || !qkv || !cos_t || !sin_t || !step) return LDM_E_BADARG;
+  return ldm_gemm_mfma256_bf16_qkv_rope(T, D, K, hd, seq, x, ldx, Wqkv, ldw, bias, cos_t, sin_t, step, q_scale, qkv,
+                                        ld_qkv, (hipStream_t)stream);
+}
+
+extern "C" int ldm_abi_version(void) { return 14; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

@@ -55,6 +55,12 @@ struct MArgs {
   int64_t gate_off;   // RES 2: columns of the gate half in R and C (R = [a | g], C = [da | dg])
                       // RES 3: rows of the gate weights in B = [w1; w2] and columns of g in C = [a | g]
   void *C2; int64_t ldc2;   // RES 3: h = a * silu(g), [M, gate_off]
+  // RES 4 (q/k/v projection with the rotary embedding in the epilogue): fp32 tables [rope_S, rope_hd/2],
+  // rope_step = [cos(16 theta_d) | sin(16 theta_d)] (2 x rope_hd/2), rope_D = H * hd columns per third
+  const float *rope_cos, *rope_sin, *rope_step;
+  int rope_hd, rope_S;
+  int64_t rope_D;
+  float rope_qscale;
   int tiles_m, tiles_n, splits;
   // optional device-side sizes (a row count known only on the GPU): rows >= *dyn_m of A/C do
   // not exist; K is *dyn_k rounded up to 32 (the caller zero-fills the rounding rows);
@@ -104,6 +110,42 @@ __device__ __forceinline__ void stage_ptrs(const bf16_t *P, int64_t ld, int64_t 
       if (col > nrows - 8) col = nrows - 8;
       src[i] = P + (int64_t)kr * ld + col;
     }
+  }
+}
+
+// RES 4: which output column does the 16-column group `grp` (0..15) of n-tile tn hold?  Tiles over the q
+// and k thirds are fed so that accumulator fragments 0-1 of a wave hold two 16-column groups of FIRST
+// half-heads and fragments 2-3 their rotation partners hd/2 further on (same lane, same register index:
+// the rotation needs no exchange); the walk over first-half groups runs through q, then k.  Tiles over
+// the v third are identity-mapped.
+__device__ __forceinline__ int64_t rope_group_col(int tn, int grp, int64_t D, int hd) {
+  const int rope_tiles = (int)(2 * D / 256);
+  if (tn >= rope_tiles) return (int64_t)tn * 256 + grp * 16;
+  const int f = grp & 3;
+  const int gph = hd / 32;                       // 16-column groups per half head
+  int L = 2 * (4 * tn + (grp >> 2)) + (f & 1);
+  const int per_region = (int)(D / 32);
+  const int region = L >= per_region ? 1 : 0;    // 0: q, 1: k
+  L -= region * per_region;
+  const int head = L / gph, sub = L - head * gph;
+  return (int64_t)region * D + (int64_t)head * hd + sub * 16 + (f >> 1) * (hd / 2);
+}
+// first-half position (0 .. hd/2 - 16, step 16) of fragment ni (0/1) of wave-column wn in n-tile tn
+__device__ __forceinline__ int rope_group_d(int tn, int wn, int ni, int64_t D, int hd) {
+  const int gph = hd / 32;
+  int L = 2 * (4 * tn + wn) + ni;
+  const int per_region = (int)(D / 32);
+  if (L >= per_region) L -= per_region;
+  return (L % gph) * 16;
+}
+__device__ __forceinline__ void stage_ptrs_rope(const bf16_t *P, int64_t ld, int tn, int wave, int lane, int64_t D, int hd,
+                                                const bf16_t *(&src)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave + 8 * i;               // = 16-column group of the tile
+    const int r = piece * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ swz_kc(r);
+    src[i] = P + (rope_group_col(tn, piece, D, hd) + (lane >> 2)) * ld + lc * 8;
   }
 }
 
@@ -199,8 +241,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   int p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
   int np = base + (tid.split < rem ? 1 : 0);
   stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
-  stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
-                       RES == 3 ? g.gate_off : 0);
+  if constexpr (RES == 4) stage_ptrs_rope(g.B, g.ldb, tid.tn, wave, lane, g.rope_D, g.rope_hd, srcB);
+  else stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
+                            RES == 3 ? g.gate_off : 0);
 #pragma unroll
   for (int p = 0; p < 3; ++p)
     if (p < np) {
@@ -232,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     float bv[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) bv[j] = 0.f;
-    if (EPI == 0 && g.bias) {
+    if (EPI == 0 && RES != 4 && g.bias) {
       const int64_t n = nw + (lane % LPR) * CPL;
 #pragma unroll
       for (int j = 0; j < CPL; ++j)
@@ -242,7 +285,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     }
 
     // RES 3: biases of this lane's accumulator columns (fragments 0-1: a, 2-3: g of the same hidden columns)
-    f4_t bag[RES == 3 ? 4 : 1];
+    f4_t bag[(RES == 3 || RES == 4) ? 4 : 1];
+    if (RES == 4) {   // biases of this lane's accumulator columns (4 consecutive ones per fragment)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bag[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bag[i] = *reinterpret_cast<const f4_t *>(g.bias + rope_group_col(tid.tn, wn * 4 + i, g.rope_D, g.rope_hd) + (lane >> 4) * 4);
+        asm volatile("" : "+v"(bag[i]));
+      }
+    }
     if (RES == 3) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -383,6 +434,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     }
 
     [[maybe_unused]] const int tid_cur_tn = tid.tn;
+    // RES 4: bias, then (on the q and k tiles) the rotary embedding of src/transformer.py:178-185 with
+    // the query scale of :261 folded in: fragments ni and ni + 2 hold x[d] and x[d + hd/2] of the same row.
+    // cos/sin of the row's position come from the tables for the first 16-row fragment and advance by
+    // the angle-addition step (16 positions) from one fragment to the next; they are loaded HERE, before
+    // the next item's prefetch goes out, so waiting for them does not drain that prefetch.  The v tiles
+    // run the same code with cos = 1, sin = 0.
+    f4_t rcs[RES == 4 ? 2 : 1], rsn[RES == 4 ? 2 : 1], rstc[RES == 4 ? 2 : 1], rsts[RES == 4 ? 2 : 1];
+    if constexpr (RES == 4) {
+      const bool is_rope = tid.tn < (int)(2 * g.rope_D / 256);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        rcs[ni] = f4_t{1.f, 1.f, 1.f, 1.f}; rsn[ni] = f4_t{0.f, 0.f, 0.f, 0.f};
+        rstc[ni] = f4_t{1.f, 1.f, 1.f, 1.f}; rsts[ni] = f4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      if (is_rope) {
+        const int h2 = g.rope_hd / 2;
+        const int pos = (int)((m0 + wm * (MI * 16) + (lane & 15)) % g.rope_S);
+        const float sc = 2 * (4 * tid.tn + wn) < (int)(g.rope_D / 32) ? g.rope_qscale : 1.0f;   // this wave's groups are q's
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int d = rope_group_d(tid.tn, wn, ni, g.rope_D, g.rope_hd) + (lane >> 4) * 4;
+          rcs[ni] = *reinterpret_cast<const f4_t *>(g.rope_cos + (int64_t)pos * h2 + d) * sc;
+          rsn[ni] = *reinterpret_cast<const f4_t *>(g.rope_sin + (int64_t)pos * h2 + d) * sc;
+          rstc[ni] = *reinterpret_cast<const f4_t *>(g.rope_step + d);
+          rsts[ni] = *reinterpret_cast<const f4_t *>(g.rope_step + h2 + d);
+        }
+      }
+    }
     w += gridDim.x;
     const bool more = w < total;
     if (more) {
@@ -390,8 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
       np = base + (tid.split < rem ? 1 : 0);
       stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
-      stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
-                           RES == 3 ? g.gate_off : 0);
+      if constexpr (RES == 4) stage_ptrs_rope(g.B, g.ldb, tid.tn, wave, lane, g.rope_D, g.rope_hd, srcB);
+      else stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
+                                RES == 3 ? g.gate_off : 0);
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         if (p < np) {
@@ -493,14 +573,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       const int wrow = lane & 15;
       const unsigned waddr = stage_lds + wrow * 256;
       TO *crow = C + (m0 + wm * (MI * 16) + lane / LPR) * g.ldc + nw + cl * CPL;
+      if constexpr (RES == 4)   // the tile's 16-column groups are scattered over the q/k/v thirds (32-byte runs)
+        crow = C + (m0 + wm * (MI * 16) + lane / LPR) * g.ldc + rope_group_col(tid_cur_tn, wn * 4 + (cl >> 1), g.rope_D, g.rope_hd) + (cl & 1) * 8;
       const int64_t rstep = (int64_t)RPP * g.ldc;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
+        if constexpr (RES == 4) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const f4_t x1 = acc[ni][mi] + bag[ni], x2 = acc[ni + 2][mi] + bag[ni + 2];
+            const f4_t y1 = x1 * rcs[ni] - x2 * rsn[ni], y2 = x2 * rcs[ni] + x1 * rsn[ni];
+            asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + (((ni * 4 + (lane >> 4)) ^ wrow) << 4)), "v"(y1) : "memory");
+            asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + ((((ni + 2) * 4 + (lane >> 4)) ^ wrow) << 4)), "v"(y2) : "memory");
+            const f4_t c2 = rcs[ni] * rstc[ni] - rsn[ni] * rsts[ni];
+            rsn[ni] = rsn[ni] * rstc[ni] + rcs[ni] * rsts[ni];
+            rcs[ni] = c2;
+          }
+        } else {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int c4 = ni * 4 + (lane >> 4);
           f4_t a = acc[ni][mi] * g.alpha;
           asm volatile("ds_write_b128 %0, %1" ::"v"(waddr + ((c4 ^ wrow) << 4)), "v"(a) : "memory");
+        }
         }
 #pragma unroll
         for (int it = 0; it < 16 / RPP; ++it) {
@@ -570,7 +665,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
             pk[1] = pack_bf16x2(o8[2], o8[3]);
             pk[2] = pack_bf16x2(o8[4], o8[5]);
             pk[3] = pack_bf16x2(o8[6], o8[7]);
-            __builtin_nontemporal_store(pk, reinterpret_cast<u4v_t *>(crow));
+            // (RES 4 writes 32- and 64-byte runs: plain stores, so that L2 can merge them into full lines)
+            if constexpr (RES == 4) *reinterpret_cast<u4v_t *>(crow) = pk;
+            else __builtin_nontemporal_store(pk, reinterpret_cast<u4v_t *>(crow));
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0])::"memory");
             st4(crow, f4{{t[0][0] + bv[0], t[0][1] + bv[1], t[0][2] + bv[2], t[0][3] + bv[3]}});
@@ -721,6 +818,7 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.gate_off = 0;
   g.C2 = nullptr; g.ldc2 = 0;
+  g.rope_cos = g.rope_sin = g.rope_step = nullptr; g.rope_hd = 0; g.rope_S = 0; g.rope_D = 0; g.rope_qscale = 1.0f;
   g.splits = 1;
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
   g.rowsum = nullptr;
@@ -800,6 +898,30 @@ int ldm_gemm_mfma256_bf16_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void
   g.tiles_m = (int)tm;
   g.tiles_n = (int)tn;
   return launch256<true, true, 256, bf16_t, 0, 3>(g, s);
+}
+
+// q/k/v projection with the rotary embedding and the query scale applied in the epilogue:
+// qkv[T, 3D] = x W^T + b, then rotate-half RoPE on every head of the q and k thirds (position = row % S)
+// and q *= q_scale.  Full tiles only.
+int ldm_gemm_mfma256_bf16_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, int64_t S, const void *x, int64_t ldx,
+                                   const void *W, int64_t ldw, const float *bias, const float *cos_t, const float *sin_t,
+                                   const float *step, float q_scale, void *qkv, int64_t ld_qkv, hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, 0, 1, T, 3 * D, K, 1.0f, x, ldx, W, ldw, qkv, ld_qkv, bias, nullptr, 0);
+  if (rc) return rc;
+  if (T < 256 || T % 256 || D < 256 || D % 256) return LDM_E_SHAPE;
+  if (!(hd == 32 || hd == 64 || hd == 96 || hd == 128) || D % hd) return LDM_E_SHAPE;
+  // a wave's 128 rows must lie inside one sequence (the angle-addition walk does not wrap)
+  if (S < 128 || S % 128 || T % S) return LDM_E_SHAPE;
+  if (ld_qkv % 8 || ld_qkv < 3 * D) return LDM_E_ALIGN;
+  if (!cos_t || !sin_t || !step || !aligned_to(cos_t, 16) || !aligned_to(sin_t, 16) || !aligned_to(step, 16)) return LDM_E_ALIGN;
+  const int64_t tm = T / 256, tn = 3 * D / 256;
+  if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
+  g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_step = step;
+  g.rope_hd = (int)hd; g.rope_S = (int)S; g.rope_D = D; g.rope_qscale = q_scale;
+  g.tiles_m = (int)tm;
+  g.tiles_n = (int)tn;
+  return launch256<true, true, 256, bf16_t, 0, 4>(g, s);
 }
 
 // Forms with device-side sizes (see MArgs): used for the LM-head backward over the compacted

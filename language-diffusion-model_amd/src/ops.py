@@ -224,13 +224,31 @@ def _weight_bias_grads(pack, g, x_in, ld_x, T, k, dev, dt):
     return grads_w, grads_b
 
 
+FUSED_QKV_ROPE = os.environ.get("LDM_FUSED_QKV_ROPE", "1") != "0"   # rotary embedding inside the q/k/v GEMM epilogue
+
+
+class RopeSpec:
+    """What the q/k/v projection needs to apply the rotary embedding in its epilogue: fp32 tables
+    cos/sin [S, hd/2], the 16-position angle-addition step [2, hd/2], sequence length, head dim and
+    the query scale.  ``applied`` is set by the projection: True when its output holds the ROTATED,
+    scaled q and k (the attention call must then not rotate again)."""
+    __slots__ = ("cos", "sin", "step", "seq", "hd", "q_scale", "applied")
+
+    def __init__(self, cos, sin, step, seq, hd, q_scale):
+        self.cos, self.sin, self.step, self.seq, self.hd, self.q_scale = cos, sin, step, seq, hd, q_scale
+        self.applied = False
+
+
 class _PackedLinear(torch.autograd.Function):
     """y[T, n] = x[T, k] @ Wpacked^T + b (+ residual);  grads for every packed weight/bias.
 
-    ``link`` (a _HeadLink or None) is filled in for the vocabulary projection: see _HeadLink."""
+    ``link`` (a _HeadLink or None) is filled in for the vocabulary projection: see _HeadLink.
+    ``rope`` (a RopeSpec or None): the pack is [Wq; Wk; Wv] and the rotary embedding + query scale may
+    be applied in the GEMM epilogue (ldm_gemm_qkv_rope).  The backward is unchanged by that: the
+    attention backward hands back the gradient w.r.t. the projection output BEFORE the rotation."""
 
     @staticmethod
-    def forward(ctx, x2, residual, pack: PackedWeights, link, *params):
+    def forward(ctx, x2, residual, pack: PackedWeights, link, rope, *params):
         N.require_device(x2)
         w, b = pack.get()
         T, k = x2.shape
@@ -243,8 +261,20 @@ class _PackedLinear(torch.autograd.Function):
             res = _rows2d(residual)
             if res.dtype != dt:
                 res = res.to(dt)
-        _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
-              res=res, ldr=res.stride(0) if res is not None else 0, tag="gemm.fwd")
+        rc = -3
+        if (rope is not None and FUSED_QKV_ROPE and dt == torch.bfloat16 and res is None and pack.n_pad == pack.n
+                and len(pack.n_each) == 3 and pack.n_each[0] == pack.n_each[1] == pack.n_each[2]):
+            with _Timed("gemm.fwd", 2.0 * T * pack.n_pad * k):
+                rc = N.lib().ldm_gemm_qkv_rope(T, pack.n_each[0], k, rope.hd, rope.seq, x2.data_ptr(), x2.stride(0),
+                                               w.data_ptr(), k, N.ptr(b), rope.cos.data_ptr(), rope.sin.data_ptr(),
+                                               rope.step.data_ptr(), float(rope.q_scale), y.data_ptr(), pack.n_pad,
+                                               N.stream())
+            if rc not in (-2, -3):
+                N.check(rc, "ldm_gemm_qkv_rope")
+                rope.applied = True
+        if rc in (-2, -3):
+            _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
+                  res=res, ldr=res.stride(0) if res is not None else 0, tag="gemm.fwd")
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.save_for_backward(x2, w)
@@ -293,7 +323,7 @@ class _PackedLinear(torch.autograd.Function):
             _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
         grads_w, grads_b = _weight_bias_grads(pack, g, x2, x2.stride(0), T, k, g.device, dt)
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
-        return (dx, dres, None, None, *grads_w, *grads_b)
+        return (dx, dres, None, None, None, *grads_w, *grads_b)
 
 
 def _backward_compact(ctx, x2, w, dlc, rows, count):
@@ -336,17 +366,17 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
         grads_b.append(db[off:off + ne])
         off += ne
     COMPACT_STATS["used"] += 1
-    return (dx, None, None, None, *grads_w, *grads_b)
+    return (dx, None, None, None, None, *grads_w, *grads_b)
 
 
 _PackedLinear._backward_compact = staticmethod(_backward_compact)
 
 
-def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None) -> Tensor:
+def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None, rope: RopeSpec | None = None) -> Tensor:
     shape = x.shape
     x2 = _rows2d(x)
     link = _HeadLink() if pack.compact_rows else None
-    y = _PackedLinear.apply(x2, residual, pack, link, *pack.weights, *pack.biases)
+    y = _PackedLinear.apply(x2, residual, pack, link, rope, *pack.weights, *pack.biases)
     out = y.reshape(*shape[:-1], pack.n) if y.is_contiguous() else y.view(*shape[:-1], pack.n)
     if link is not None:
         out._ldm_head_link = link    # read by masked_ce when THIS tensor object is handed to the loss
@@ -707,7 +737,7 @@ class _RopeAttention(torch.autograd.Function):
     mask the kernels regenerate from ``seed`` and the element coordinates; nothing is stored."""
 
     @staticmethod
-    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin, dropout_p=0.0, seed=0):
+    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin, dropout_p=0.0, seed=0, pre_rotated=False):
         N.require_device(qkv)
         lib = N.lib()
         dt = qkv.dtype
@@ -719,9 +749,11 @@ class _RopeAttention(torch.autograd.Function):
             q2 = q2.contiguous()
         # the rotation is applied in place; the pre-rotation values are not needed again
         # (the projection's backward uses only its own input and weights)
-        with _Timed("rope", 2.0 * B * S * 2 * D * q2.element_size()):
-            N.check(lib.ldm_rope_qk(q2.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
-                                    1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
+        # (pre_rotated: the projection's epilogue has already rotated and scaled q and k)
+        if not pre_rotated:
+            with _Timed("rope", 2.0 * B * S * 2 * D * q2.element_size()):
+                N.check(lib.ldm_rope_qk(q2.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
+                                        1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
         o = torch.empty(B * S, D, dtype=dt, device=qkv.device)
         saved = torch.empty(lib.ldm_attn_saved_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
         if dropout_p > 0.0:
@@ -765,7 +797,7 @@ class _RopeAttention(torch.autograd.Function):
             if not fused:
                 N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
                                         1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
-            return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None
+            return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None, None
         # attention backward with the rotary backward fused into its stores where the kernel has it
         rc = -3
         if FUSED_UNROPE and dt == torch.bfloat16:
@@ -781,16 +813,19 @@ class _RopeAttention(torch.autograd.Function):
                     "ldm_attn_bwd")
             N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
                                     1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
-        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None
+        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None, None
 
 
 def rope_attention(qkv: Tensor, key_valid: Tensor | None, B: int, S: int, H: int, hd: int, cos: Tensor,
-                   sin: Tensor, dropout_p: float = 0.0, seed: int | None = None) -> Tensor:
+                   sin: Tensor, dropout_p: float = 0.0, seed: int | None = None, pre_rotated: bool = False) -> Tensor:
     """``dropout_p`` > 0: attention-probability dropout; ``seed`` (63 bits) defaults to a draw from
-    torch's CPU generator, so ``torch.manual_seed`` reproduces the masks."""
+    torch's CPU generator, so ``torch.manual_seed`` reproduces the masks.  ``pre_rotated``: q and k in
+    ``qkv`` already carry the rotary embedding and the query scale (the projection applied them); the
+    gradient handed back is still the one w.r.t. the un-rotated projection output."""
     if dropout_p > 0.0 and seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin, float(dropout_p), int(seed or 0))
+    return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin, float(dropout_p), int(seed or 0),
+                                bool(pre_rotated))
 
 
 # ----------------------------------------------------------------------------

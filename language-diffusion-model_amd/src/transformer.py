@@ -21,6 +21,7 @@ autocast).  Parameters are always fp32 masters.
 
 from __future__ import annotations
 
+import math
 import os
 from dataclasses import dataclass
 
@@ -113,6 +114,7 @@ class RotaryPositionEmbedding(nn.Module):
         self.cached_cos: Tensor | None = None
         self.cached_sin: Tensor | None = None
         self._half: tuple[Tensor, Tensor] | None = None
+        self._step: Tensor | None = None
 
     def forward(self, x: Tensor, seq_len: int) -> tuple[Tensor, Tensor]:
         if seq_len > self.max_seq_len:
@@ -127,6 +129,10 @@ class RotaryPositionEmbedding(nn.Module):
             self.cached_sin = emb.sin()
             half = freqs.shape[-1]
             self._half = (self.cached_cos[:, :half].contiguous(), self.cached_sin[:, :half].contiguous())
+            # cos / sin of a 16-position advance, per rotation pair (double precision, then fp32): the
+            # projection epilogue steps down its rows with it (ops.RopeSpec)
+            ang = 16.0 * self.inv_freq.to(device=x.device, dtype=torch.float64)
+            self._step = torch.stack((ang.cos(), ang.sin())).to(torch.float32).contiguous()
         assert self.cached_cos is not None and self.cached_sin is not None
         return self.cached_cos, self.cached_sin
 
@@ -135,6 +141,12 @@ class RotaryPositionEmbedding(nn.Module):
         self.forward(x, seq_len)
         assert self._half is not None
         return self._half
+
+    def step_table(self, x: Tensor, seq_len: int) -> Tensor:
+        """fp32 [2, dim/2]: cos and sin of the angle of 16 positions, per rotation pair."""
+        self.forward(x, seq_len)
+        assert self._step is not None
+        return self._step
 
     @staticmethod
     def apply_rotary_pos_emb(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor) -> tuple[Tensor, Tensor]:
@@ -193,10 +205,15 @@ class RotaryMultiheadAttention(nn.Module):
             key_valid = getattr(key_padding_mask, "_ldm_key_valid", None)
             if key_valid is None:
                 key_valid = _key_valid_bytes(key_padding_mask)
-        qkv = ops.packed_linear(query, self._pack("qkv"))
+        # the rotary embedding and q / sqrt(hd) (src/transformer.py:255-261) ride in the projection's
+        # epilogue where the kernel takes the shape; otherwise the attention call rotates in place
+        rope = ops.RopeSpec(cos, sin, self.rotary_emb.step_table(query, seq), seq, self.head_dim,
+                            1.0 / math.sqrt(self.head_dim))
+        qkv = ops.packed_linear(query, self._pack("qkv"), rope=rope)
         # dropout on the attention probabilities (src/transformer.py:278) happens inside the kernels
         p_drop = self.dropout.p if self.training else 0.0
-        attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin, dropout_p=p_drop)
+        attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin, dropout_p=p_drop,
+                                  pre_rotated=rope.applied)
         return ops.packed_linear(attn, self._pack("out"), residual=residual)
 
 

@@ -714,3 +714,89 @@ def test_swiglu_module_fused_up_projection_matches_two_pass(dev):
     assert rel_err(out[True][1], out[False][1]) < 6e-3
     for n in out[True][2]:
         assert rel_err(out[True][2][n], out[False][2][n]) < 6e-3, n
+
+
+# ------------------------------------------------------------------ q/k/v projection with the rotary embedding in its epilogue
+@pytest.mark.parametrize("T,S,H,hd,K", [(512, 512, 8, 96, 768), (1024, 128, 2, 128, 256), (512, 256, 4, 64, 320),
+                                        (256, 128, 8, 32, 64), (4096, 4096, 16, 128, 512)])
+def test_gemm_qkv_rope_epilogue(dev, T, S, H, hd, K):
+    """ldm_gemm_qkv_rope against fp64 arithmetic (x W^T + b, then q*cos + rotate_half(q)*sin on the q and k
+    thirds at position row % S, q / sqrt(hd): src/transformer.py:242-261) and against what ldm_gemm followed
+    by ldm_rope_qk leaves; a row stride wider than 3D; shapes the kernel must decline."""
+    from oracle import step_oracle as so
+    from src import _native as N
+    lib = N.lib()
+    D = H * hd
+    torch.manual_seed(T + hd)
+    x = torch.randn(T, K, device=dev).bfloat16()
+    W = (torch.randn(3 * D, K, device=dev) / math.sqrt(K)).bfloat16()
+    b = torch.randn(3 * D, device=dev)
+    cos, sin = so.rope_tables(S, hd)
+    ch, sh = cos[:, :hd // 2].contiguous().to(dev), sin[:, :hd // 2].contiguous().to(dev)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).double() / hd))
+    step = torch.stack(((16 * inv_freq).cos(), (16 * inv_freq).sin())).float().contiguous().to(dev)
+    scale = 1.0 / math.sqrt(hd)
+    ld = 3 * D + 64
+    out = torch.full((T, ld), 7.0, device=dev).bfloat16()
+    rc = lib.ldm_gemm_qkv_rope(T, D, K, hd, S, x.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), ch.data_ptr(), sh.data_ptr(),
+                               step.data_ptr(), scale, out.data_ptr(), ld, N.stream())
+    assert rc == 0, rc
+    # fp64 reference
+    y = x.double() @ W.double().t() + b.double()
+    pos = torch.arange(T, device=dev) % S
+    c = cos.double().to(dev)[pos][:, None, :]
+    s_ = sin.double().to(dev)[pos][:, None, :]
+
+    def rot(v):
+        v = v.reshape(T, H, hd)
+        a, bb = v.chunk(2, dim=-1)
+        return (v * c + torch.cat((-bb, a), dim=-1) * s_).reshape(T, D)
+    ref = torch.cat((rot(y[:, :D]) * scale, rot(y[:, D:2 * D]), y[:, 2 * D:]), dim=1)
+    for name, sl in (("q", slice(0, D)), ("k", slice(D, 2 * D)), ("v", slice(2 * D, 3 * D))):
+        assert rel_err(out[:, sl].float(), ref[:, sl]) < 4e-3, name       # one bf16 rounding of the result
+    assert torch.all(out[:, 3 * D:] == 7.0)                                # columns past 3D untouched
+    # the two-call form (rounds q, k to bf16 before rotating): equal up to that extra rounding
+    two = torch.empty(T, 3 * D, device=dev, dtype=torch.bfloat16)
+    N.check(lib.ldm_gemm(N.BF16, N.BF16, 0, 1, T, 3 * D, K, 1.0, x.data_ptr(), K, W.data_ptr(), K, two.data_ptr(), 3 * D,
+                         b.data_ptr(), None, 0, N.stream()), "ldm_gemm")
+    N.check(lib.ldm_rope_qk(two.data_ptr(), N.BF16, T // S, S, H, hd, 3 * D, ch.data_ptr(), sh.data_ptr(), scale, 0,
+                            N.stream()), "ldm_rope_qk")
+    assert rel_err(out[:, :3 * D].float(), two.float()) < 8e-3
+    assert rel_err(two.float(), ref) >= rel_err(out[:, :3 * D].float(), ref) * 0.9    # the fused form is not the less accurate one
+    # declined shapes: ragged T, S that is not a multiple of 128, an unsupported head dim
+    assert lib.ldm_gemm_qkv_rope(T - 8, D, K, hd, S, x.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), ch.data_ptr(),
+                                 sh.data_ptr(), step.data_ptr(), scale, out.data_ptr(), ld, N.stream()) == -3
+    assert lib.ldm_gemm_qkv_rope(T, D, K, hd, 100, x.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), ch.data_ptr(),
+                                 sh.data_ptr(), step.data_ptr(), scale, out.data_ptr(), ld, N.stream()) == -3
+
+
+def test_attention_module_fused_qkv_rope_matches_two_pass(dev):
+    """RotaryMultiheadAttention with the rotary embedding in the projection epilogue and with the separate
+    in-place pass: same output and the same gradients up to bf16 rounding."""
+    from src import ops
+    from src.transformer import RotaryMultiheadAttention
+    torch.manual_seed(1)
+    m = RotaryMultiheadAttention(768, 8, dropout=0.0).to(dev)
+    m.compute_dtype = torch.bfloat16
+    B, S = 2, 512
+    x = torch.randn(B, S, 768, device=dev).bfloat16()
+    go = torch.randn(B, S, 768, device=dev).bfloat16()
+    kpm = torch.zeros(B, S, dtype=torch.bool, device=dev)
+    kpm[1, 400:] = True
+    out = {}
+    for fused in (True, False):
+        ops.FUSED_QKV_ROPE = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_(True)
+            y = m(xx, xx, xx, key_padding_mask=kpm)
+            y.backward(go)
+        finally:
+            ops.FUSED_QKV_ROPE = True
+        out[fused] = (y.detach().float(), xx.grad.float(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert rel_err(out[True][0], out[False][0]) < 8e-3
+    assert rel_err(out[True][1], out[False][1]) < 1e-2
+    for n in out[True][2]:
+        if n == "k_proj.bias":
+            continue
+        assert rel_err(out[True][2][n], out[False][2][n]) < 1e-2, n
