@@ -200,8 +200,8 @@ int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
  * reference's masked_fill(-inf) at :271-274).  q is expected pre-scaled.
  * q, k, v are read from a fused [B*S, 3*H*hd] activation (ld_qkv elements per row;
  * q at column 0, k at H*hd, v at 2*H*hd); o is [B*S, H*hd] (ld_o).
- * `saved` keeps what backward needs: BF16: fp32 log-sum-exp [B,H,S] followed by the bf16
- * rounding residual of o (o_exact - o, [B*S, H*hd]; the backward forms rowsum(do * o) from o plus
+ * `saved` keeps what backward needs: BF16: fp32 log-sum-exp [B,H,S] followed by the
+ * rounding residual of o (o_exact - o as fp8, in a kernel-private layout; the backward forms rowsum(do * o) from o plus
  * this residual -- with the rounded o alone the q/k gradients of deep layers carry about three times
  * the error of the reference under bf16 autocast); F32: the probabilities [B,H,S,S].
  * Size: ldm_attn_saved_bytes().  `saved` must be 16-byte aligned.

@@ -1,15 +1,30 @@
 // C-ABI attention dispatch: BF16 -> flash kernels, F32 -> materialised-score path.
 #include "common.h"
 #include "attn.h"
+#include <stdlib.h>
 
-// BF16 `saved`: fp32 log-sum-exp [B,H,S], then (256-byte aligned) the bf16 rounding residual of O,
-// [B*S, H*hd], which the backward adds to O when it forms delta = rowsum(dO * O)
+// BF16 `saved`: fp32 log-sum-exp [B,H,S], then (256-byte aligned) the bf16 rounding residual of O in a
+// layout private to the kernels, which the backward adds to O when it forms delta = rowsum(dO * O)
+// LDM_ATTN_OLO=0: do not write / use the residual of O (A/B measurements of its cost and of its effect)
+static bool olo_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("LDM_ATTN_OLO");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
 static int64_t lse_bytes(int64_t batch, int64_t nhead, int64_t seq) {
   return (batch * nhead * seq * (int64_t)sizeof(float) + 255) / 256 * 256;
 }
 
 extern "C" int64_t ldm_attn_saved_bytes(int dtype, int64_t batch, int64_t nhead, int64_t seq, int64_t hd) {
-  if (dtype == LDM_BF16) return lse_bytes(batch, nhead, seq) + batch * seq * nhead * hd * 2;
+  if (dtype == LDM_BF16) {
+    // residual of O: one slot of DP (head dim rounded up to 32/64/96/128) per row of every 128-row block
+    const int64_t dp = hd <= 32 ? 32 : hd <= 64 ? 64 : hd <= 96 ? 96 : 128;
+    return lse_bytes(batch, nhead, seq) + batch * nhead * ((seq + 127) / 128) * 128 * dp;   // one byte per element
+  }
   return batch * nhead * seq * seq * (int64_t)sizeof(float);
 }
 
@@ -36,7 +51,8 @@ static int attn_fwd_impl(int dtype, const void *qkv, int64_t ld_qkv, const uint8
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LDM_BF16)
     return ldm_flash_fwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (bf16_t *)o, ld_o,
-                              (float *)saved, (bf16_t *)((char *)saved + lse_bytes(batch, nhead, seq)), thresh, seed, s);
+                              (float *)saved, olo_enabled() ? (bf16_t *)((char *)saved + lse_bytes(batch, nhead, seq)) : nullptr,
+                              thresh, seed, s);
   if (dtype == LDM_F32)
     return ldm_attn_fwd_f32((const float *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (float *)o, ld_o,
                             (float *)saved, (float *)ws, thresh, seed, s);
@@ -71,7 +87,8 @@ static int attn_bwd_impl(int dtype, const void *qkv, int64_t ld_qkv, const uint8
   if (dtype == LDM_BF16)
     return ldm_flash_bwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (const bf16_t *)o,
                               (const bf16_t *)do_, ld_o, (const float *)saved,
-                              (const bf16_t *)((const char *)saved + lse_bytes(batch, nhead, seq)), (bf16_t *)dqkv,
+                              olo_enabled() ? (const bf16_t *)((const char *)saved + lse_bytes(batch, nhead, seq)) : nullptr,
+                              (bf16_t *)dqkv,
                               (float *)ws, rope_cos, rope_sin, rope_scale, thresh, seed, s);
   if (rope_cos) return LDM_E_SHAPE;
   if (dtype == LDM_F32)

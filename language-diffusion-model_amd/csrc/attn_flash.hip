@@ -44,8 +44,10 @@ struct FArgs {
   int B, H, S, hd;
   bf16_t *o; const bf16_t *o_in; const bf16_t *dout; int64_t ld_o;
   float *lse; const float *lse_in;
-  // O - bf16(O), itself rounded to bf16, [B*S, H*hd] contiguous: written by the forward, read by the dQ
-  // kernel, so that delta = rowsum(dO * O) is formed from O to ~16 mantissa bits.  With the stored
+  // O - bf16(O), as fp8: written by the forward, read by the dQ kernel, so that delta = rowsum(dO * O) is
+  // formed from O to ~12 mantissa bits.  Layout: private to the two kernels, one byte per element,
+  // [workgroup (batch, head, 128-row block)][wave][lane][DP / 2] in the forward's accumulator order (both
+  // kernels give lane (c, half) of wave w the row 128 blk + 32 w + c): DP / 32 16-byte stores per lane.  With the stored
   // bf16 O alone the error of delta is the SAME for every key of a query row and does not average out
   // over the keys in dQ: the q/k projection gradients of deep layers then carry 3x the error the
   // reference has under bf16 autocast (measured; its softmax backward sums P * dP in fp32).
@@ -254,40 +256,73 @@ __device__ __forceinline__ void unrope_acc(f16_t (&acc)[AT<DP>::ND], float scale
   }
 }
 
-// O_lo = O - bf16(O) of a wave's 32 x DP output tile (see FArgs::o_lo); same store path as O itself
+// O_lo = O - bf16(O) of this lane's share of the output tile (see FArgs::o_lo), stored as OCP fp8 (e4m3)
+// of O_lo * 2^12: the residual is at most 2^-9 of |O|, so three more mantissa bits on it take the error
+// of delta from 2^-9 to 2^-13 of |O| |dO|, below every other rounding of the backward, at one byte per
+// element.  Bytes 8 kk .. 8 kk + 7 of the lane's slot are head-dim positions 16 kk + 8 half + 0..7.
+constexpr float OLO_SCALE = 4096.0f, OLO_INV = 1.0f / 4096.0f;
 template <int DP>
-__device__ __forceinline__ void store_rounding_residual(const FArgs &a, f16_t (&oacc)[AT<DP>::ND], float inv_l, char *wlds,
-                                                        int b, int head, int q0, int q, int lane, int half) {
+__device__ __forceinline__ void store_rounding_residual(const FArgs &a, const f16_t (&oacc)[AT<DP>::ND], float inv_l,
+                                                        const Blk &blk, int wave, int lane) {
+  const int nblk = (a.S + 127) / 128;
+  // a lane holds half of its row: DP / 2 bytes per lane, 64 * DP per workgroup
+  unsigned char *slot = reinterpret_cast<unsigned char *>(a.o_lo) +
+                        (((((int64_t)blk.b * a.H + blk.head) * nblk + blk.blk) * 4 + wave) * 64 + lane) * (DP / 2);
 #pragma unroll
-  for (int i = 0; i < AT<DP>::ND; ++i)
+  for (int db = 0; db < AT<DP>::ND; ++db) {
+    unsigned w[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = oacc[i][r] * inv_l;
-      oacc[i][r] = v - bf16_to_f32(f32_to_bf16(v));
+    for (int q = 0; q < 4; ++q) {
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = oacc[db][4 * q + j] * inv_l;
+        r[j] = (v - bf16_to_f32(f32_to_bf16(v))) * OLO_SCALE;
+      }
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], pk, true);
+      w[q] = (unsigned)pk;
     }
-  const int64_t D = (int64_t)a.H * a.hd;
-  if (aligned_to_dev(a.o_lo, 16))
-    store_tile_lds<DP>(wlds, a.o_lo + ((int64_t)b * a.S + q0) * D + (int64_t)head * a.hd, D, oacc, 1.0f, lane, a.S - q0, a.hd);
-  else if (q < a.S)
-    store_rows<DP>(a.o_lo + ((int64_t)b * a.S + q) * D + (int64_t)head * a.hd, oacc, 1.0f, half, a.hd);
+    // w[q] = positions 32 db + 8 q + 4 half + 0..3.  Swapping the upper half-wave of w[2p] with the lower
+    // half-wave of w[2p+1] leaves lane (c, half) with positions 32 db + 16 p + 8 half + 0..7 in
+    // (w[2p], w[2p+1]): the k-operand order in which the dQ kernel holds dO (16 kk + 8 half + 0..7, kk = 2 db + p)
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(w[2 * p2], w[2 * p2 + 1], false, false);
+      w[2 * p2] = sw[0];
+      w[2 * p2 + 1] = sw[1];
+    }
+    *reinterpret_cast<uint4 *>(slot + db * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
 }
 
-// sum over this lane's head-dim slice of o_lo[row] * dO[row] (see FArgs::o_lo); 0 without the residual
-template <int NK>
-__device__ __forceinline__ float delta_residual(const bf16_t *o_lo, const bf8_t (&dof)[NK], int64_t row_off, int half, int hd) {
+// This lane's part of rowsum(o_lo[row] * dO[row]) (see FArgs::o_lo) against the dO fragments the lane already
+// holds (dof[kk] = positions 16 kk + 8 half + 0..7); the caller's cross-half add completes the row.
+template <int DP>
+__device__ __forceinline__ float delta_residual(const FArgs &a, const Blk &blk, int wave, int lane,
+                                                const bf8_t (&dof)[AT<DP>::NK]) {
   float acc = 0.f;
-  if (o_lo) {
-    const bf16_t *p = o_lo + row_off + 8 * half;
+  if (a.o_lo_in) {
+    const int nblk = (a.S + 127) / 128;
+    const unsigned char *slot = reinterpret_cast<const unsigned char *>(a.o_lo_in) +
+                                (((((int64_t)blk.b * a.H + blk.head) * nblk + blk.blk) * 4 + wave) * 64 + lane) * (DP / 2);
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-      if (16 * kk + 8 * half < hd) {
-        const bf8_t olf = __builtin_bit_cast(bf8_t, *reinterpret_cast<const uint4 *>(p + 16 * kk));
+    for (int db = 0; db < AT<DP>::ND; ++db) {
+      const uint4 lo = *reinterpret_cast<const uint4 *>(slot + db * 16);
+      const unsigned lw[4] = {lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf((float)olf[j], (float)dof[kk][j], acc);
+      for (int q = 0; q < 4; ++q) {
+        const int kk = 2 * db + (q >> 1), j0 = 4 * (q & 1);
+        const auto r01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lw[q], false);
+        const auto r23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lw[q], true);
+        acc = fmaf(r01[0], (float)dof[kk][j0 + 0], acc);
+        acc = fmaf(r01[1], (float)dof[kk][j0 + 1], acc);
+        acc = fmaf(r23[0], (float)dof[kk][j0 + 2], acc);
+        acc = fmaf(r23[1], (float)dof[kk][j0 + 3], acc);
       }
     }
   }
-  return acc;
+  return acc * OLO_INV;
 }
 
 // --------------------------------------------------------------------------- forward
@@ -456,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(FArgs a) {
                          oacc, inv_l, lane, S - q0, hd);
     else if (q < S)
       store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, inv_l, half, hd);
-    if (a.o_lo) store_rounding_residual<DP>(a, oacc, inv_l, smem + wave * 32 * T::RSTR, b, head, q0, q, lane, half);
+    if (a.o_lo) store_rounding_residual<DP>(a, oacc, inv_l, blk, wave, lane);
   }
 #ifdef LDM_ATTN_TIMING
   if (a.timing && tid == 0 && blockIdx.x == 8) {
@@ -731,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
                          oacc, inv_l, lane, S - q0, hd);
     else if (q < S)
       store_rows<DP>(a.o + ((int64_t)b * S + q) * a.ld_o + (int64_t)head * hd, oacc, inv_l, half, hd);
-    if (a.o_lo) store_rounding_residual<DP>(a, oacc, inv_l, smem + wave * 32 * T::RSTR, b, head, q0, q, lane, half);
+    if (a.o_lo) store_rounding_residual<DP>(a, oacc, inv_l, blk, wave, lane);
   }
 #ifdef LDM_ATTN_TIMING
   if (a.timing && tid == 0 && blockIdx.x == 8) {
@@ -781,7 +816,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
-  dsum += delta_residual<T::NK>(a.o_lo_in, dof, (int64_t)b * S * D + (int64_t)head * hd + (int64_t)qc * D, half, hd);
+  dsum += delta_residual<DP>(a, blk, wave, lane, dof);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
@@ -1058,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
   }
-  dsum += delta_residual<T::NK>(a.o_lo_in, dof, (int64_t)b * S * D + (int64_t)head * hd + (int64_t)qc * D, half, hd);
+  dsum += delta_residual<DP>(a, blk, wave, lane, dof);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
