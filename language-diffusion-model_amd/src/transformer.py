@@ -278,6 +278,10 @@ class DiffusionTransformer(nn.Module):
         self.compute_dtype = _default_dtype()
         self.hot_token_id = 103   # embedding-gradient rows of this id are pre-reduced per workgroup
         self._packs: dict = {}
+        # True: keep only each layer's INPUT for backward and re-run the layer's forward there
+        # (torch.utils.checkpoint): activation memory per layer drops from ~19 [T, d]-sized tensors to one,
+        # for one extra forward pass.  Meant for the 8B shape at long batch; off by default.
+        self.recompute_layers = False
 
     def _init_parameters(self) -> None:
         """Xavier-uniform on every parameter with dim() > 1 (src/transformer.py:407-411)."""
@@ -306,6 +310,19 @@ class DiffusionTransformer(nn.Module):
         if attention_mask is not None:
             key_padding_mask = attention_mask == 0
             key_padding_mask._ldm_key_valid = _key_valid_bytes(key_padding_mask)   # shared by all layers
+        if self.recompute_layers and torch.is_grad_enabled() and self.training:
+            from torch.utils.checkpoint import checkpoint
+            key_valid = None if key_padding_mask is None else key_padding_mask._ldm_key_valid
+
+            def run(layer, x_in):
+                kpm = None
+                if key_padding_mask is not None:      # tensor attributes do not survive the checkpoint's re-run
+                    kpm = attention_mask == 0
+                    kpm._ldm_key_valid = key_valid
+                return layer(x_in, src_key_padding_mask=kpm)
+            for layer in self.layers:
+                x = checkpoint(run, layer, x, use_reentrant=False)
+            return self.norm(x)
         for layer in self.layers:
             x = layer(x, src_key_padding_mask=key_padding_mask)
         return self.norm(x)

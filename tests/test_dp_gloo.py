@@ -97,3 +97,47 @@ def test_bucketed_allreduce_two_ranks():
     for r in range(2):
         for n, g in res[r][0][2].items():
             assert torch.allclose(torch.from_numpy(g), 2 * want[n], rtol=1e-6, atol=1e-7), ("deferred", r, n)
+
+
+def _worker_bf16_wire(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from src.dp import GradBucketDataParallel
+    torch.manual_seed(0)
+    net = _Net()
+    dp = GradBucketDataParallel(net, bucket_bytes=1024, wire_dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(5 + rank, 16, generator=g)
+    dp(x, True).pow(2).mean().backward()
+    q.put((rank, {n: p.grad.clone().numpy() for n, p in net.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_bf16_wire():
+    """Gradient buckets exchanged in bf16 (half the bytes over the links): every rank ends with the same
+    fp32 gradients, equal to the mean of the per-rank gradients up to one bf16 rounding per rank and one of
+    the sum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_bf16_wire, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, grads = q.get(timeout=120)
+        res[rank] = grads
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {}
+    for r in range(2):
+        for n, g in _local_grads(r, True).items():
+            want[n] = want.get(n, 0) + g / 2
+    for n in want:
+        a, b = torch.from_numpy(res[0][n]), torch.from_numpy(res[1][n])
+        assert torch.equal(a, b), n
+        err = float((a - want[n]).norm() / max(float(want[n].norm()), 1e-30))
+        assert err < 1e-2, (n, err)

@@ -241,3 +241,88 @@ def test_two_models_interleaved_do_not_cross_wires(dev):
             if n.endswith("k_proj.bias"):
                 continue
             assert rel_err(p.grad, ref[n]) < 5e-3, n       # float-atomic summation order only
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_recompute_layers_gives_the_same_step(dev, mode):
+    """DiffusionTransformer.recompute_layers (keep only each layer's input, re-run its forward in backward):
+    same loss, same gradients up to the run-to-run noise of the float-atomic weight gradients."""
+    from oracle import step_oracle as so
+    ocfg = so.OracleConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=3, dim_feedforward=1024)
+    params = so.init_params(ocfg, seed=21)
+    B, S = 2, 512
+    ids, att = so.synthetic_batch(B, S, 30522, seed=22, ragged=True, dirty=True)
+    draw = torch.rand(B, S, generator=torch.Generator().manual_seed(23)).to(dev)
+    dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+    model = _model_from(params, ocfg, dev, dtype, 512)
+    model.masking_strategy = _InjectedDraw(model.masking_strategy, draw)
+    out = {}
+    for rc in (False, True):
+        model.transformer.recompute_layers = rc
+        model.transformer.zero_grad(set_to_none=True)
+        loss = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([0.5]))
+        loss.backward()
+        out[rc] = (loss.item(), {n: p.grad.detach().clone() for n, p in model.transformer.named_parameters()})
+    assert out[True][0] == out[False][0]
+    for n, g in out[False][1].items():
+        if n.endswith("k_proj.bias"):
+            continue
+        assert rel_err(out[True][1][n], g) < (1e-6 if mode == "fp32" else 5e-3), n
+
+
+def test_8b_layer_shape_two_layers(dev):
+    """The LLaDA-8B layer shape (d=4096, 32 heads of 128, ff=12288, V=126464) at two layers on one GPU:
+    against the fp32 oracle at S=1024 (loss and whole gradient 2e-2 in bf16), and at S=4096 the
+    size-independent properties -- fused head loss == dense composition, loss near ln(V) at random init,
+    activation recompute changes nothing."""
+    from oracle import step_oracle as so
+    from src.loss import variational_lower_bound_loss
+    ocfg = so.OracleConfig(vocab_size=126464, d_model=4096, nhead=32, num_layers=2, dim_feedforward=12288)
+    params = so.init_params(ocfg, seed=31)
+    torch.set_num_threads(16)
+    S = 1024
+    ids, att = so.synthetic_batch(1, S, 126464, seed=32, ragged=False, dirty=True)
+    att[0, 900:] = 0
+    ids[0, 899] = 102
+    ids[0, 900:] = 0
+    draw = torch.rand(1, S, generator=torch.Generator().manual_seed(33))
+    ol, og, _, _, _ = so.step_loss_and_grads(params, ocfg, ids, att, 0.6, draw)
+    model = _model_from(params, ocfg, dev, torch.bfloat16, 4096)
+    del params
+    model.masking_strategy = _InjectedDraw(model.masking_strategy, draw.to(dev))
+    loss = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([0.6]))
+    loss.backward()
+    _compare(model, og, ol, loss.item(), 2e-2, "8b-2layer/bf16/S1024")     # flat 2e-2, per tensor too
+    del og
+    # S = 4096, ragged
+    S = 4096
+    g = torch.Generator().manual_seed(34)
+    ids = torch.randint(1000, 126464, (1, S), generator=g)
+    ids[:, 0] = 101
+    att = (torch.arange(S)[None, :] < 3500).long()
+    ids = torch.where(att == 1, ids, torch.zeros_like(ids)).to(dev)
+    att = att.to(dev)
+    model.masking_strategy = model.masking_strategy.inner
+    tr = model.transformer
+    res = {}
+    for kind in ("fused", "dense", "recompute"):
+        tr.recompute_layers = kind == "recompute"
+        tr.zero_grad(set_to_none=True)
+        torch.manual_seed(7)                       # same mask draw in every run
+        if kind == "dense":
+            logits, masked, _ = model(ids, att, t=torch.tensor([0.3]))
+            l = variational_lower_bound_loss(logits, ids, masked, 103, att)
+        else:
+            l = model.training_loss(ids, att, t=torch.tensor([0.3]))
+        l.backward()
+        res[kind] = (l.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()})
+        del l
+        torch.cuda.empty_cache()
+    assert abs(res["fused"][0] - math.log(126464)) < 1.5
+    assert abs(res["fused"][0] - res["dense"][0]) <= 1e-5 * abs(res["dense"][0])
+    assert res["fused"][0] == res["recompute"][0]
+    for n, gd in res["dense"][1].items():
+        if n.endswith("k_proj.bias"):
+            continue
+        assert rel_err(res["fused"][1][n], gd) < 5e-3, n
+        assert rel_err(res["recompute"][1][n], res["fused"][1][n]) < 5e-3, n
