@@ -92,9 +92,17 @@ class GradBucketDataParallel(nn.Module):
         self.defer_scale = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         # identical starting point on every rank (DDP broadcasts rank 0's state too)
-        # gloo cannot be trusted with device memory here (two ranks sharing one GPU stall inside
-        # its device path): with that backend the payload is staged through host memory.
-        self._host_staged = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
+        # gloo + device tensors: the payload is staged through host memory HERE, on the current stream,
+        # and gloo is handed a host tensor.  gloo's own device path (pinned staging on its side streams,
+        # completion events recorded from its worker thread) completes isolated collectives between two
+        # processes that share a GPU (scripts/gloo_dev_bcast_probe.py), but the pattern of this wrapper --
+        # dozens of back-to-back broadcasts with no device synchronisation in between, then asynchronous
+        # all-reduces issued from autograd hooks -- does not return on this ROCm stack (observed twice:
+        # both ranks parked in broadcast()'s wait).  gloo never exchanges device handles, so this is not
+        # an IPC matter, and the RCCL path (the one a multi-GPU node runs) is not involved.
+        # LDM_DP_HOST_STAGE=0 hands gloo the device tensors (for re-testing on another stack).
+        self._host_staged = (dist.is_initialized() and dist.get_backend(process_group) == "gloo"
+                             and os.environ.get("LDM_DP_HOST_STAGE", "1") != "0")
         if self.world_size > 1:
             src = dist.get_global_rank(process_group, 0) if process_group else 0
             for t in list(module.parameters()) + list(module.buffers()):
