@@ -578,12 +578,17 @@ class _SwiGLUUp(torch.autograd.Function):
         ctx.pack = pack
         ctx.save_for_backward(x2, w)
         ctx.mark_non_differentiable(h)
+        # without this autograd hands backward a zero tensor of h's shape for the non-differentiable output:
+        # a [T, F] fill per layer and step
+        ctx.set_materialize_grads(False)
         return (y[:, :pack.n] if pack.n != pack.n_pad else y), h
 
     @staticmethod
     def backward(ctx, gy, _gh):
         x2, w = ctx.saved_tensors
         pack = ctx.pack
+        if gy is None:
+            return (None, None) + (None,) * (2 * len(pack.weights))
         dt = pack.dtype
         T, k = x2.shape
         n, n_pad = pack.n, pack.n_pad
