@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-2 check: GPU tests (incl. the not-yet-collected no-alloc test by name), smoke, bench with and without launch events.
+# Round-2 check: GPU tests , smoke, bench with and without launch events.
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1000 python -u -m pytest tests tests/wip_no_alloc.py -m gpu -q --tb=short -s --timeout 400 --timeout-method thread -p no:cacheprovider > gpurun_out/tests.log 2>&1
+timeout -k 10 1000 python -u -m pytest tests -m gpu -q --tb=short -s --timeout 400 --timeout-method thread -p no:cacheprovider > gpurun_out/tests.log 2>&1
 rc=$?; echo "pytest rc=$rc"; grep -E "^(FAILED|ERROR)|passed|failed|^\[" gpurun_out/tests.log | cut -c1-300 | tail -40
 [ $rc -ne 0 ] && exit 1
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { echo SMOKE FAILED; tail -5 gpurun_out/smoke.log; exit 1; }
