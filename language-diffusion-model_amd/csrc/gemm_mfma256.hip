@@ -27,6 +27,7 @@
 // The swizzle is applied to the per-lane SOURCE address of the LDS-DMA (its LDS
 // destination is lane-linear) and again on the read.
 #include "common.h"
+#include <type_traits>
 #include "gemm.h"
 #include <stdlib.h>
 
@@ -42,7 +43,8 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256;
 constexpr int KH = 32;                 // k depth of a half-tile
-constexpr int LDS_BYTES = 128 * 1024;  // ring of 4 half-tiles (128 or 96 KiB) + 32 KiB epilogue staging (inside slot 3 at BN = 256)
+constexpr int NSLOT = 5;               // ring slots (half-tiles)
+constexpr int LDS_BYTES = 160 * 1024;  // ring of 5 half-tiles (160 or 120 KiB) + 32 KiB epilogue staging (inside slot 4 at BN = 256)
 
 struct MArgs {
   int64_t M, N, K;
@@ -156,6 +158,26 @@ __device__ __forceinline__ void stage_issue(const bf16_t *(&src)[NP], int64_t ko
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + koff), LDS_PTR(img + (wave + 8 * i) * 1024), 16, 0, 0);
 }
 
+// Two consecutive half-tiles of one operand, piece by piece: for a K-contiguous operand the two 64-byte
+// row segments are the halves of one 128-byte line, and requested back to back by the same wave the
+// second is served from the vector L1 instead of by a second trip to L2 (measured L2->LDS rate of one CU:
+// 72 GB/s for the halves a phase apart, 135 GB/s back to back).
+template <int NP>
+__device__ __forceinline__ void stage_issue_pair(const bf16_t *(&src)[NP], int64_t koff0, int64_t koff1, char *img0,
+                                                 char *img1, int wave) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + koff0), LDS_PTR(img0 + (wave + 8 * i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + koff1), LDS_PTR(img1 + (wave + 8 * i) * 1024), 16, 0, 0);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // 16 (rows or cols) x 32 k fragment of a half-tile image
 template <bool KC, int ROWS>
 __device__ __forceinline__ bf8_t read_frag(const char *img, int rbase, int lane) {
@@ -173,6 +195,37 @@ __device__ __forceinline__ bf8_t read_frag(const char *img, int rbase, int lane)
     s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0 + 4 * RB));
     s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf8_t, v);
+  }
+}
+
+// The strided-operand fragment as two transposing reads written as asm: behind the compiler's own
+// transposing-read intrinsic every LDS-DMA in flight is drained first (s_waitcnt vmcnt(0): it cannot
+// see that the slot being read and the slots being filled are disjoint), which costs the ring its depth.
+// The values exist only after the s_waitcnt lgkmcnt that tr_done() is placed behind.
+template <int ROWS>
+__device__ __forceinline__ void tr_issue(unsigned img_lds, int rbase, int lane, s4_t &lo, s4_t &hi) {
+  constexpr int RB = ROWS * 2;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int kr0 = 8 * g + q;
+  const int ch = ((rbase >> 3) + (p >> 1)) ^ swz_st(kr0);
+  const unsigned a0 = img_lds + kr0 * RB + (ch << 4) + ((p & 1) << 3);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "n"(4 * RB));
+}
+template <int N>
+__device__ __forceinline__ void tr_done(s4_t (&lo)[N], s4_t (&hi)[N], bf8_t (&f)[N]) {
+  static_assert(N == 2 || N == 4 || N == 8, "fragment count");
+  if constexpr (N == 2)
+    asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(hi[0]), "+v"(hi[1]));
+  else if constexpr (N == 4)
+    asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+  else
+    asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                      "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    s8_t v = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+    f[i] = __builtin_bit_cast(bf8_t, v);
   }
 }
 
@@ -202,8 +255,12 @@ __device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int
 
 // BN: 256 (waves 2M x 4N, 128x64 per wave) or 128 (waves 4M x 2N, 64x64 per wave).
 // PERSISTENT: gridDim.x workgroups (one per CU) walk the work items w = blockIdx.x,
-// blockIdx.x + gridDim.x, ...; the LDS-DMA of the NEXT item's first three half-tiles is issued
+// blockIdx.x + gridDim.x, ...; the LDS-DMA of the NEXT item's first four half-tiles is issued
 // before the epilogue of the current one, so the store tail and the load latency overlap.
+// Half-tiles of a K-contiguous operand travel in PAIRS (2q, 2q+1): the first two pairs before the item
+// starts, pair (p+3, p+4) at the start of the MFMA segment of every odd phase p, into the ring slots of
+// half-tiles p-2 and p-1.  Half-tiles of a strided operand (whole 128-byte lines per piece anyway) travel singly,
+// half-tile p+3 in phase p.
 template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, int RES = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   constexpr int WN_ = BN / 64;            // waves along N
@@ -213,9 +270,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   constexpr int PA = BM / 128, PB = BN / 128;   // LDS-DMA pieces per wave per half-tile
   constexpr int HT_A = BM * 64, HT_B = BN * 64; // bytes of one half-tile image
   constexpr int HT = HT_A + HT_B;
-  constexpr int P = PA + PB;
-  // epilogue staging (8 waves x 4 KiB): ring slot 3 when it is 32 KiB, else behind the ring
-  constexpr int STAGE_OFF = (HT >= 32768) ? 3 * HT : 4 * HT;
+  // epilogue staging (8 waves x 4 KiB): ring slot 4 when a slot is 32 KiB, else behind the ring
+  constexpr int STAGE_OFF = (HT >= 32768) ? (NSLOT - 1) * HT : NSLOT * HT;
+  static_assert(STAGE_OFF + 32768 <= LDS_BYTES, "ring + staging exceed the LDS allocation");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -244,16 +301,63 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   if constexpr (RES == 4) stage_ptrs_rope(g.B, g.ldb, tid.tn, wave, lane, g.rope_D, g.rope_hd, srcB);
   else stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
                             RES == 3 ? g.gate_off : 0);
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-    if (p < np) {
-      stage_issue<PA>(srcA, (int64_t)(p_begin + p) * kstepA, smem + p * HT, wave);
-      stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
-    }
+  // Per half-tile a wave issues SI instructions for the operands that travel singly, and per pair PI
+  // for those that travel in pairs.
+  constexpr bool PAIR_A = A_KC, PAIR_B = B_KC;
+  constexpr int SI = (PAIR_A ? 0 : PA) + (PAIR_B ? 0 : PB);
+  constexpr int PI = (PAIR_A ? 2 * PA : 0) + (PAIR_B ? 2 * PB : 0);
+  // Half of one operand's fragments is read in segment M (under the first MFMAs): half of A, or, when
+  // both operands travel in pairs, half of B.  A pair's second slot is that of half-tile p-1, which the
+  // other half of the workgroup (one barrier behind) may still be reading in ITS segment M while this
+  // half is in segment R: the pair of the operand that is read in segment M goes out in segment M (once a
+  // wave is there, every wave has left phase p-1), the other operand's pair in segment R.
+  constexpr bool SPLIT_B = PAIR_A && PAIR_B, SPLIT_A = !SPLIT_B;
+  constexpr bool A_PAIR_M = PAIR_A && SPLIT_A, B_PAIR_M = PAIR_B && SPLIT_B;
+  constexpr int PR = (PAIR_A && !A_PAIR_M ? 2 * PA : 0) + (PAIR_B && !B_PAIR_M ? 2 * PB : 0);   // pair instructions sent in R
+  typedef std::integral_constant<bool, !A_PAIR_M> a_in_r_t;
+  typedef std::integral_constant<bool, !B_PAIR_M> b_in_r_t;
+  typedef std::integral_constant<bool, A_PAIR_M> a_in_m_t;
+  typedef std::integral_constant<bool, B_PAIR_M> b_in_m_t;
+  // Element offsets into A and B of the half-tile that segment R of the current phase sends (p + 3):
+  // advanced by one k step per phase (scalar adds instead of 64-bit multiplies in every phase).
+  int64_t offA = 0, offB = 0;
+  // pair of the half-tiles at offsets (oa0, ob0) and (oa1, ob1) into ring slots s0, s1
+  auto issue_pair_at = [&](auto do_a, auto do_b, int64_t oa0, int64_t oa1, int64_t ob0, int64_t ob1, int s0, int s1) {
+    if constexpr (PAIR_A && decltype(do_a)::value) stage_issue_pair<PA>(srcA, oa0, oa1, smem + s0 * HT, smem + s1 * HT, wave);
+    if constexpr (PAIR_B && decltype(do_b)::value)
+      stage_issue_pair<PB>(srcB, ob0, ob1, smem + s0 * HT + HT_A, smem + s1 * HT + HT_A, wave);
+  };
+  auto issue_single_at = [&](int64_t oa, int64_t ob, int s0) {
+    if constexpr (!PAIR_A) stage_issue<PA>(srcA, oa, smem + s0 * HT, wave);
+    if constexpr (!PAIR_B) stage_issue<PB>(srcB, ob, smem + s0 * HT + HT_A, wave);
+  };
+  // by half-tile index; a half-tile past the item's last one is a second request of the last one (same
+  // instruction count for the counted waits; its slot is free)
+  auto issue_pair = [&](int h, int s0, int s1) {
+    const int h0 = h < np ? h : np - 1, h1 = h + 1 < np ? h + 1 : np - 1;
+    issue_pair_at(std::true_type{}, std::true_type{}, (int64_t)(p_begin + h0) * kstepA, (int64_t)(p_begin + h1) * kstepA, (int64_t)(p_begin + h0) * kstepB,
+                  (int64_t)(p_begin + h1) * kstepB, s0, s1);
+  };
+  auto issue_single = [&](int h, int s0) {
+    const int h0 = h < np ? h : np - 1;
+    issue_single_at((int64_t)(p_begin + h0) * kstepA, (int64_t)(p_begin + h0) * kstepB, s0);
+  };
+  // before an item starts: pairs (0,1) and (2,3), then the single half-tiles 0, 1, 2
+  auto issue_first = [&]() {
+    if (np <= 0) return;
+    issue_pair(0, 0, 1);
+    issue_pair(2, 2, 3);
+    issue_single(0, 0);
+    issue_single(1, 1);
+    issue_single(2, 2);
+    offA = (int64_t)(p_begin + 3) * kstepA;
+    offB = (int64_t)(p_begin + 3) * kstepB;
+  };
+  issue_first();
 
   // stores per wave in the fast-path epilogue (16 bytes per lane each)
   constexpr int NST = RES == 3 ? MI * 3 : MI * (sizeof(TO) == 2 ? 2 : 4) * (RES == 2 ? 2 : 1);
-  static_assert(2 * P + NST <= 63, "vmcnt is a 6-bit counter");
+  static_assert(2 * PI + 3 * SI + NST <= 63, "vmcnt is a 6-bit counter");
 #ifdef LDM_GEMM_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long te0 = 0, te1 = 0;
@@ -318,20 +422,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     for (int j = 0; j < RS; ++j) racc[j] = f4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = EPI == 1 && g.rowsum != nullptr && tid.tn == 0;
 
-    // half-tile 0 landed for everybody (also: everybody has left the previous epilogue).
-    // After a fast-path epilogue exactly NST stores of this wave are YOUNGER than the three
-    // half-tiles prefetched before it (vmcnt counts loads and stores together, in issue
-    // order): counting them in lets the first two phases start while those stores drain.
+    // half-tiles 0 and 1 landed for everybody (also: everybody has left the previous epilogue).
+    // After a fast-path epilogue exactly NST stores of this wave are YOUNGER than the two
+    // pairs prefetched before it (vmcnt counts loads and stores together, in issue
+    // order): counting them in lets the first phases start while those stores drain.
     TSTAMP(te1);
 #ifdef LDM_GEMM_TIMING
     if (te0) tacc[6] += te1 - te0;   // previous item's epilogue (+ next item's set-up and prefetch issue)
 #endif
-    const bool carry = carry_next && np > 3;
+    const bool carry = carry_next;
     carry_next = false;
-    if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NST) : "memory");
-    else if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-    else if (np > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // younger than the last piece of half-tile 0: single half-tiles 1 and 2, or else pair (2,3)
+    constexpr int W0 = SI > 0 ? 2 * SI : PI;
+    if (carry) wait_vm<W0 + NST>(); else wait_vm<W0>();
     __builtin_amdgcn_s_barrier();
 
     // The two halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run ONE
@@ -346,25 +449,70 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
 #ifdef LDM_GEMM_TIMING
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
 #endif
+    int slot = 0;   // ring slot of half-tile p
     for (int p = 0; p < np; ++p) {
       TSTAMP(t0);
-      // ---- segment R: retire this wave's pieces of half-tile p+1, read p, refill the slot of p-1
-      if (carry && p < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NST) : "memory");
-      else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-      else if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      TSTAMP(t1);
-      const char *cur = smem + (p & 3) * HT;
-      bf8_t fa[MI], fb[NI];
+      // ---- segment R: read p; in odd phases send pair (p+3, p+4) into the slots of p-2 and p-1 and
+      // retire this wave's pieces of pair (p+1, p+2), which the next two phases read
+      const char *cur = smem + slot * HT;
+      // fragments: (see SPLIT_A / SPLIT_B) the second half of one operand is requested at the start of
+      // segment M and arrives under the first half's MFMAs
+      constexpr int MH = SPLIT_A ? MI / 2 : MI, NH = SPLIT_B ? NI / 2 : NI;
+      bf8_t fa[MH], fa2[SPLIT_A ? MH : 1], fb[NH], fb2[SPLIT_B ? NH : 1];
+      [[maybe_unused]] s4_t alo[MH], ahi[MH], alo2[SPLIT_A ? MH : 1], ahi2[SPLIT_A ? MH : 1], blo[NH], bhi[NH];
+      [[maybe_unused]] const unsigned cur_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + slot * HT;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) fb[i] = read_frag<B_KC, BN>(cur + HT_A, wn * 64 + i * 16, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_KC, BM>(cur, wm * (MI * 16) + i * 16, lane);
-      if (p + 3 < np) {
-        char *slot = smem + ((p + 3) & 3) * HT;
-        stage_issue<PA>(srcA, (int64_t)(p_begin + p + 3) * kstepA, slot, wave);
-        stage_issue<PB>(srcB, (int64_t)(p_begin + p + 3) * kstepB, slot + HT_A, wave);
+      for (int i = 0; i < NH; ++i) {
+        if constexpr (B_KC) fb[i] = read_frag<true, BN>(cur + HT_A, wn * 64 + i * 16, lane);
+        else tr_issue<BN>(cur_lds + HT_A, wn * 64 + i * 16, lane, blo[i], bhi[i]);
       }
+#pragma unroll
+      for (int i = 0; i < MH; ++i) {
+        if constexpr (A_KC) fa[i] = read_frag<true, BM>(cur, wm * (MI * 16) + i * 16, lane);
+        else tr_issue<BM>(cur_lds, wm * (MI * 16) + i * 16, lane, alo[i], ahi[i]);
+      }
+      // row sums: this wave's RS fragments of opA are read a second time, in segment M (the choice depends
+      // on the wave, and choosing among registers costs a chain of branches in every phase)
+      [[maybe_unused]] bf8_t fr[RS];
+      [[maybe_unused]] s4_t rlo[RS], rhi[RS];
+      {
+        const int rem = np - p;             // half-tiles left, this one included
+        const bool more3 = rem > 3;
+        const int s3 = slot + 3 >= NSLOT ? slot + 3 - NSLOT : slot + 3;
+        if (SI > 0 && more3) issue_single_at(offA, offB, s3);
+        if (PR > 0 && (p & 1) && more3)
+          issue_pair_at(a_in_r_t{}, b_in_r_t{}, offA, rem > 4 ? offA + kstepA : offA, offB, rem > 4 ? offB + kstepB : offB, s3,
+                        s3 + 1 >= NSLOT ? 0 : s3 + 1);
+        // Retire this wave's pieces of half-tile p+1.  Issue order: before the item P01 P23 S0 S1 S2 (then
+        // the previous item's NST stores, if carried), then per phase q: S(q+3) in segment R and, q odd,
+        // P(q+3, q+4), one operand's part in segment R and the other's in segment M.  Younger than the
+        // last piece of half-tile p+1 are therefore: the singles of p+2 and p+3, in even phases the pairs
+        // sent in the phase before, and in odd phases the part of the pair just sent in segment R.
+        TSTAMP(t1);
+        constexpr int PODD = PR;
+        if (p >= 2) {
+          if (rem > 3) {
+            if (p & 1) wait_vm<2 * SI + PODD>(); else wait_vm<2 * SI + PI>();
+          } else if (rem == 3) {
+            if (p & 1) wait_vm<SI>(); else wait_vm<SI + PI>();
+          } else {
+            wait_vm<0>();
+          }
+        } else if (p == 1) {
+          if (rem > 3) { if (carry) wait_vm<2 * SI + PODD + NST>(); else wait_vm<2 * SI + PODD>(); }
+          else if (rem == 3) { if (carry) wait_vm<SI + NST>(); else wait_vm<SI>(); }
+          else { if (carry) wait_vm<NST>(); else wait_vm<0>(); }
+        } else {
+          // p == 0: younger than S1 are S2, [stores], S3; without singles, younger than P01 is P23
+          constexpr int Y0 = SI > 0 ? SI : PI;
+          if (rem > 3) { if (carry) wait_vm<Y0 + SI + NST>(); else wait_vm<Y0 + SI>(); }
+          else { if (carry) wait_vm<Y0 + NST>(); else wait_vm<Y0>(); }
+        }
+      }
+      slot = slot + 1 >= NSLOT ? 0 : slot + 1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of half-tile p are complete
+      if constexpr (!B_KC) tr_done<NH>(blo, bhi, fb);
+      if constexpr (!A_KC) tr_done<MH>(alo, ahi, fa);
       TSTAMP(t2);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -372,17 +520,68 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       TSTAMP(t3);
       // ---- segment M
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (SPLIT_A) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int i = 0; i < MH; ++i) {
+          if constexpr (A_KC) fa2[i] = read_frag<true, BM>(cur, wm * (MI * 16) + (MH + i) * 16, lane);
+          else tr_issue<BM>(cur_lds, wm * (MI * 16) + (MH + i) * 16, lane, alo2[i], ahi2[i]);
+        }
+      } else {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        for (int i = 0; i < NH; ++i) fb2[i] = read_frag<true, BN>(cur + HT_A, wn * 64 + (NH + i) * 16, lane);
+      }
       if (EPI == 1 && do_rowsum) {
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+          if constexpr (A_KC) fr[j] = read_frag<true, BM>(cur, wm * (MI * 16) + (wn * RS + j) * 16, lane);
+          else tr_issue<BM>(cur_lds, wm * (MI * 16) + (wn * RS + j) * 16, lane, rlo[j], rhi[j]);
+        }
+      }
+      if (PI - PR > 0 && (p & 1) && p + 3 < np) {
+        const int s3 = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;   // (slot already names half-tile p+1)
+        const bool two = p + 4 < np;
+        issue_pair_at(a_in_m_t{}, b_in_m_t{}, offA, two ? offA + kstepA : offA, offB, two ? offB + kstepB : offB, s3,
+                      s3 + 1 >= NSLOT ? 0 : s3 + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the requests above stay ahead of the MFMAs
+      offA += kstepA;
+      offB += kstepB;
+      asm volatile("" : "+s"(offA), "+s"(offB));   // stay scalar (else: one running VGPR pointer pair per piece)
+      if constexpr (SPLIT_A) {
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        if constexpr (!A_KC) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          tr_done<MH>(alo2, ahi2, fa2);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ni][MH + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa2[mi], acc[ni][MH + mi], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[NH + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb2[ni], fa[mi], acc[NH + ni][mi], 0, 0, 0);
+      }
+      if (EPI == 1 && do_rowsum) {
+        if constexpr (!A_KC) {
+          if constexpr (!SPLIT_A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          tr_done<RS>(rlo, rhi, fr);
+        }
         const bf8_t ones = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          if (mi / RS == wn)
-            racc[mi % RS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[mi], racc[mi % RS], 0, 0, 0);
+        for (int j = 0; j < RS; ++j) racc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[j], racc[j], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
       TSTAMP(t4);
@@ -391,18 +590,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       __builtin_amdgcn_sched_barrier(0);
 #ifdef LDM_GEMM_TIMING
       TSTAMP(t5);
-      tacc[0] += t1 - t0;   // counted vmcnt wait
-      tacc[1] += t2 - t1;   // LDS reads + LDS-DMA issue + lgkmcnt(0)
+      tacc[0] += t1 - t0;   // LDS reads + LDS-DMA issue (the stamp waits for the reads)
+      tacc[1] += t2 - t1;   // counted vmcnt wait
       tacc[2] += t3 - t2;   // barrier after R
       tacc[3] += t4 - t3;   // MFMA issue
       tacc[4] += t5 - t4;   // barrier after M
       tacc[5] += 1;         // phases
 #endif
     }
+    if (np < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the second prologue pair was never waited for)
     if (!late) __builtin_amdgcn_s_barrier();
     TSTAMP(te0);
     // All reads of the ring are complete for every wave (lgkmcnt(0) before each barrier) and
-    // no LDS-DMA is outstanding: slots 0-2 can take the next item's first half-tiles now.
+    // no LDS-DMA is outstanding: slots 0-3 can take the next item's first half-tiles now.
 
     // Fast-path epilogue with a residual (bf16 output): the residual rows of this wave's tile are
     // loaded 16 bytes per lane exactly where the stores will go, in batches of RQ loads held in two
@@ -472,12 +672,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       if constexpr (RES == 4) stage_ptrs_rope(g.B, g.ldb, tid.tn, wave, lane, g.rope_D, g.rope_hd, srcB);
       else stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
                                 RES == 3 ? g.gate_off : 0);
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        if (p < np) {
-          stage_issue<PA>(srcA, (int64_t)(p_begin + p) * kstepA, smem + p * HT, wave);
-          stage_issue<PB>(srcB, (int64_t)(p_begin + p) * kstepB, smem + p * HT + HT_A, wave);
-        }
+      issue_first();
     }
 
     if (EPI == 1 && do_rowsum && lane < 16) {

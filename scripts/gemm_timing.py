@@ -8,16 +8,20 @@ os.environ["LDM_GEMM_TIMING_BUF"] = str(buf.data_ptr())
 os.environ["LDM_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                      "language-diffusion-model_amd", "lib", "libldm_hip_timing.so")
 from src import _native as N
-T = 32768
-names = ["vmcnt wait", "reads+issue", "barrier R", "mfma", "barrier M"]
+T = int(os.environ.get("T", 32768))
+names = ["reads+issue", "vmcnt wait", "barrier R", "mfma", "barrier M"]
 for tag, ta, tb, M, Nn, K in [("fwd qkv", 0, 1, T, 2304, 768), ("fwd head", 0, 1, T, 30528, 768),
-                              ("dx qkv", 0, 0, T, 768, 2304), ("dw head", 1, 0, 30528, 768, T)]:
+                              ("dx qkv", 0, 0, T, 768, 2304), ("dw qkv", 1, 0, 2304, 768, T),
+                              ("dw head", 1, 0, 30528, 768, T)]:
     a = torch.randn((K, M) if ta else (M, K), device=dev).bfloat16()
     b = torch.randn((Nn, K) if tb else (K, Nn), device=dev).bfloat16()
     acc = tag.startswith("dw")
     c = torch.zeros(M, Nn, device=dev, dtype=torch.float32 if acc else torch.bfloat16)
+    rs = torch.zeros(M, device=dev)
     def run():
-        if acc:
+        if acc and os.environ.get("ROWSUM"):
+            N.check(N.lib().ldm_gemm_acc_rowsum(ta, tb, M, Nn, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), Nn, rs.data_ptr(), N.stream()), "acc_rowsum")
+        elif acc:
             N.check(N.lib().ldm_gemm_acc(1, ta, tb, M, Nn, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), Nn, N.stream()), "acc")
         else:
             N.check(N.lib().ldm_gemm(1, 1, ta, tb, M, Nn, K, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), Nn, None, None, 0, N.stream()), "gemm")
