@@ -537,6 +537,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           else tr_issue<BM>(cur_lds, wm * (MI * 16) + (wn * RS + j) * 16, lane, rlo[j], rhi[j]);
         }
       }
+      // (Measured: sending this part of the pair behind the first eight MFMAs, or one instruction at a time
+      // between groups of four MFMAs, or starting the segment with four MFMAs, is no faster than this.)
       if (PI - PR > 0 && (p & 1) && p + 3 < np) {
         const int s3 = slot + 2 >= NSLOT ? slot + 2 - NSLOT : slot + 2;   // (slot already names half-tile p+1)
         const bool two = p + 4 < np;
@@ -544,9 +546,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
                       s3 + 1 >= NSLOT ? 0 : s3 + 1);
       }
       __builtin_amdgcn_sched_barrier(0);   // the requests above stay ahead of the MFMAs
-      offA += kstepA;
-      offB += kstepB;
-      asm volatile("" : "+s"(offA), "+s"(offB));   // stay scalar (else: one running VGPR pointer pair per piece)
       if constexpr (SPLIT_A) {
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi)
@@ -574,6 +573,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           for (int mi = 0; mi < MI; ++mi)
             acc[NH + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb2[ni], fa[mi], acc[NH + ni][mi], 0, 0, 0);
       }
+      offA += kstepA;
+      offB += kstepB;
+      asm volatile("" : "+s"(offA), "+s"(offB));   // stay scalar (else: one running VGPR pointer pair per piece)
       if (EPI == 1 && do_rowsum) {
         if constexpr (!A_KC) {
           if constexpr (!SPLIT_A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

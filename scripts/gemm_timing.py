@@ -34,6 +34,10 @@ for tag, ta, tb, M, Nn, K in [("fwd qkv", 0, 1, T, 2304, 768), ("fwd head", 0, 1
     print(f"{tag}: {us:.1f} us, {2.0 * M * Nn * K / us / 1e6:.0f} TF (instrumented); main-loop cycles of one workgroup {cyc:.0f} -> >= {cyc / us / 1e3:.2f} GHz")
     ntile = t[0, 5].item() / (K // 32)
     print(f"  per tile: main loop {t[0, :5].sum().item() / ntile:.0f}  epilogue+setup {t[0, 6].item() / max(ntile - 1, 1):.0f}  first-data wait {t[0, 7].item() / ntile:.0f}   (wave 4: {t[4, 6].item() / max(ntile - 1, 1):.0f} / {t[4, 7].item() / ntile:.0f})")
+    if os.environ.get("TIMING_M"):   # library built with -DLDM_GEMM_TIMING_M: slots 6/7 = first 16 MFMAs / wait for the second half
+        for w in (0, 4):
+            n = t[w, 5].item()
+            print(f"  wave {w}: segment M: first-half MFMAs {t[w, 6].item() / n:7.1f}  wait for second-half fragments {t[w, 7].item() / n:7.1f}")
     for w in (0, 4):
         n = t[w, 5].item()
         print(f"  wave {w}: " + "  ".join(f"{names[i]} {t[w, i].item() / n:7.1f}" for i in range(5)) + f"   total/phase {t[w, :5].sum().item() / n:7.1f}  phases {int(n)}")
