@@ -64,6 +64,7 @@ struct MArgs {
   int64_t rope_D;
   float rope_qscale;
   int tiles_m, tiles_n, splits;
+  int band_m;   // m-tiles per band of the tile walk (see decode_item)
   // optional device-side sizes (a row count known only on the GPU): rows >= *dyn_m of A/C do
   // not exist; K is *dyn_k rounded up to 32 (the caller zero-fills the rounding rows);
   // row_map sends output row m to C row row_map[m]
@@ -233,7 +234,7 @@ __device__ __forceinline__ void tr_done(s4_t (&lo)[N], s4_t (&hi)[N], bf8_t (&f)
 // XCD (shared L2), so each of the 8 groups gets a contiguous run of items; tiles are walked
 // in bands of 4 m-tiles.
 struct TileId { int split, tm, tn; };
-__device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int tiles_n) {
+__device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int tiles_n, int GM) {
   {
     const int q = total >> 3, r = total & 7, x = w & 7;
     w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (w >> 3);
@@ -242,7 +243,6 @@ __device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int
   TileId t;
   t.split = w / ntiles;
   w -= t.split * ntiles;
-  const int GM = 4;
   const int width = GM * tiles_n;
   const int grp = w / width;
   const int first = grp * GM;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
 
   int w = blockIdx.x;
   if (w >= total) return;   // workgroup-uniform
-  TileId tid = decode_item(w, total, tiles_m, g.tiles_n);
+  TileId tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
 
   const bf16_t *srcA[PA], *srcB[PB];
   int p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     w += gridDim.x;
     const bool more = w < total;
     if (more) {
-      tid = decode_item(w, total, tiles_m, g.tiles_n);
+      tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
       p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
       np = base + (tid.split < rem ? 1 : 0);
       stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
@@ -1000,6 +1000,11 @@ int dispatch_layout(const MArgs &g, bool akc, bool bkc, hipStream_t s) {
   return launch256<false, false, BN, TO, EPI>(g, s);
 }
 
+int gm_band_env() {
+  static const int v = getenv("LDM_GEMM_BAND") ? atoi(getenv("LDM_GEMM_BAND")) : 0;
+  return v;
+}
+
 int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
          int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, const float *bias, const void *R,
          int64_t ldr) {
@@ -1017,6 +1022,15 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.C2 = nullptr; g.ldc2 = 0;
   g.rope_cos = g.rope_sin = g.rope_step = nullptr; g.rope_hd = 0; g.rope_S = 0; g.rope_D = 0; g.rope_qscale = 1.0f;
   g.splits = 1;
+  // m-tiles per band of the tile walk: the band's A panel (band x 256 rows x K) is sized to about 6 MB,
+  // within 2..16 (measured on one box at M = 262144: K = 768 prefers 8-16 m-tiles, -11 % at N = 2048 and
+  // -6 % at N = 1024 against 4; K >= 2048 prefers 2-4; experiments: LDM_GEMM_BAND)
+  const int gm_env = gm_band_env();
+  {
+    int b = 16;
+    while (b > 2 && (int64_t)b * 512 * K > (int64_t)8 << 20) b >>= 1;
+    g.band_m = gm_env > 0 ? gm_env : b;
+  }
   g.dyn_m = g.dyn_k = g.row_map = nullptr;
   g.rowsum = nullptr;
   static const char *tb = getenv("LDM_GEMM_TIMING_BUF");
@@ -1116,6 +1130,9 @@ int ldm_gemm_mfma256_bf16_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, 
   if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
   g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_step = step;
   g.rope_hd = (int)hd; g.rope_S = (int)S; g.rope_D = D; g.rope_qscale = q_scale;
+  // narrow bands: the attention kernel that follows reads q, k, v of whole sequences, and finds more of
+  // them in cache when the rows were written band by band (measured in the step: 5.45 against 5.56 ms)
+  if (gm_band_env() <= 0) g.band_m = 4;
   g.tiles_m = (int)tm;
   g.tiles_n = (int)tn;
   return launch256<true, true, 256, bf16_t, 0, 4>(g, s);
@@ -1167,6 +1184,7 @@ int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N,
   g.splits = best;
   g.dyn_k = dyn_k;
   g.rowsum = rowsum;
+  if (gm_band_env() <= 0) g.band_m = 4;   // few, long work items: the band height does not matter (measured)
   const bool akc = !transA, bkc = transB != 0;
   return use128 ? dispatch_layout<128, float, 1>(g, akc, bkc, s) : dispatch_layout<256, float, 1>(g, akc, bkc, s);
 }
@@ -1209,6 +1227,7 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
   if (!worth && !force) return LDM_E_SHAPE;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn; g.splits = (int)splits;
   g.rowsum = rowsum;
+  if (gm_band_env() <= 0) g.band_m = 4;   // few, long work items: the band height does not matter (measured)
   const bool akc = !transA, bkc = transB != 0;
   return use128 ? dispatch_layout<128, float, 1>(g, akc, bkc, s) : dispatch_layout<256, float, 1>(g, akc, bkc, s);
 }
