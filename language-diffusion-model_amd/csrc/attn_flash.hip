@@ -549,9 +549,17 @@ struct TileDma {
   }
   // piece i of tile t -> image `img`; rows >= S re-read row S-1 (finite values; masked later)
   __device__ __forceinline__ void issue_one(int i, int t, int S, int64_t ld, char *img, int wave) const {
-    const int lim = S - 64 * t;
-    const bf16_t *src = p[i] + (int64_t)t * step;
-    if (lim < 64) src -= (int64_t)(row0[i] >= lim ? row0[i] - (lim - 1) : 0) * ld;   // lim is wave-uniform
+    const int lim = S - 64 * t;            // wave-uniform
+    int64_t toff = (int64_t)t * step;      // a scalar product; one 64-bit add per lane below
+    asm volatile("" : "+s"(toff));
+    const bf16_t *src = p[i] + toff;
+    if (__builtin_expect(lim < 64, 0)) {
+      // the last, partial tile only.  The empty asm keeps this a branch: as a select the clamp costs every
+      // tile of every piece two quarter-rate integer multiplies and a 64-bit multiply-add per lane
+      // (about a third of the vector work of a forward tile at head dim 96).
+      asm volatile("" : "+v"(src));
+      src -= (int64_t)(row0[i] >= lim ? row0[i] - (lim - 1) : 0) * ld;
+    }
     __builtin_amdgcn_global_load_lds(GLB_PTR2(src), LDS_PTR2(img + (wave * L::PW + i) * 1024), 16, 0, 0);
   }
   __device__ __forceinline__ void issue(int t, int S, int64_t ld, char *img, int wave) const {

@@ -28,6 +28,8 @@
 // destination is lane-linear) and again on the read.
 #include "common.h"
 #include <type_traits>
+#include <vector>
+#include <stdio.h>
 #include "gemm.h"
 #include <stdlib.h>
 
@@ -977,8 +979,36 @@ int num_cus() {
   return n;
 }
 
+// Experiments: LDM_GEMM_BAND_MAP="res:epi:K:N=band,..." (N = 0: any) overrides the band height per call site.
+int band_override(int res, int epi, int64_t K, int64_t N) {
+  struct Ent { int res, epi; long long k, n; int band; };
+  static std::vector<Ent> *tab = nullptr;
+  static bool parsed = false;
+  if (!parsed) {
+    parsed = true;
+    if (const char *e = getenv("LDM_GEMM_BAND_MAP")) {
+      tab = new std::vector<Ent>();
+      const char *p = e;
+      while (*p) {
+        Ent t;
+        int used = 0;
+        if (sscanf(p, "%d:%d:%lld:%lld=%d%n", &t.res, &t.epi, &t.k, &t.n, &t.band, &used) == 5) tab->push_back(t);
+        else break;
+        p += used;
+        if (*p == ',') ++p;
+      }
+    }
+  }
+  if (!tab) return 0;
+  for (const Ent &t : *tab)
+    if (t.res == res && t.epi == epi && t.k == K && (t.n == 0 || t.n == N)) return t.band;
+  return 0;
+}
+
 template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, int RES = 0>
-int launch256(const MArgs &g, hipStream_t s) {
+int launch256(const MArgs &g_in, hipStream_t s) {
+  MArgs g = g_in;
+  if (const int b = band_override(RES, EPI, g.K, g.N)) g.band_m = b;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)gemm256_k<A_KC, B_KC, BN, TO, EPI, RES>,
