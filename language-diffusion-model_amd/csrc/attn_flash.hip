@@ -856,10 +856,26 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
       f16_t sacc, dpacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      // the K and V row fragments are requested AHK k-steps ahead of the MFMAs that take them
+#ifdef LDM_DQ_AHEAD
+      constexpr int AHK = LDM_DQ_AHEAD;
+#else
+      constexpr int AHK = 2;
+#endif
+      bf8_t kfr[T::NK], vfr[T::NK];
+#pragma unroll
+      for (int kk = 0; kk < AHK; ++kk) {
+        kfr[kk] = row_frag2<DP>(Kt, kbk * 32 + c, kk, half);
+        vfr[kk] = row_frag2<DP>(Vt, kbk * 32 + c, kk, half);
+      }
 #pragma unroll
       for (int kk = 0; kk < T::NK; ++kk) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Kt, kbk * 32 + c, kk, half), qf[kk], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Vt, kbk * 32 + c, kk, half), dof[kk], dpacc, 0, 0, 0);
+        if (kk + AHK < T::NK) {
+          kfr[kk + AHK] = row_frag2<DP>(Kt, kbk * 32 + c, kk + AHK, half);
+          vfr[kk + AHK] = row_frag2<DP>(Vt, kbk * 32 + c, kk + AHK, half);
+        }
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kk], qf[kk], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kk], dof[kk], dpacc, 0, 0, 0);
         if (kbk == 0 && kk < 2 * Lay<DP>::PW && more) {
           constexpr int PW = Lay<DP>::PW;
           if (kk < PW) kd.issue_one(kk, t + 1, S, a.ld, nb, wave);
@@ -983,14 +999,16 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     const unsigned qo = lds_off(Qt), go = lds_off(Gt);
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
-      f16_t sacc, dpacc;
+      // the score accumulator starts at -lse and the dP accumulator at -delta: the products then leave
+      // s - lse and dP - delta, with no register copy of the statistics beside them
+      f16_t s0, dpacc;
       [[maybe_unused]] float nd[16];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const float4 l4 = *reinterpret_cast<const float4 *>(lse_s + qbk * 32 + 8 * r4 + 4 * half);
         const float4 d4 = *reinterpret_cast<const float4 *>(dlt_s + qbk * 32 + 8 * r4 + 4 * half);
-        sacc[4 * r4 + 0] = -l4.x * LOG2E; sacc[4 * r4 + 1] = -l4.y * LOG2E;
-        sacc[4 * r4 + 2] = -l4.z * LOG2E; sacc[4 * r4 + 3] = -l4.w * LOG2E;
+        s0[4 * r4 + 0] = -l4.x; s0[4 * r4 + 1] = -l4.y;
+        s0[4 * r4 + 2] = -l4.z; s0[4 * r4 + 3] = -l4.w;
         if constexpr (DROP) {   // the mask applies to dP alone: -delta is added after the products
           nd[4 * r4 + 0] = -d4.x; nd[4 * r4 + 1] = -d4.y; nd[4 * r4 + 2] = -d4.z; nd[4 * r4 + 3] = -d4.w;
           dpacc[4 * r4 + 0] = 0.f; dpacc[4 * r4 + 1] = 0.f; dpacc[4 * r4 + 2] = 0.f; dpacc[4 * r4 + 3] = 0.f;
@@ -998,13 +1016,27 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
           dpacc[4 * r4 + 0] = -d4.x; dpacc[4 * r4 + 1] = -d4.y; dpacc[4 * r4 + 2] = -d4.z; dpacc[4 * r4 + 3] = -d4.w;
         }
       }
-      f16_t s0;
+      // the Q and dO row fragments are requested AHQ k-steps ahead of the MFMAs that take them (head dim 96
+      // runs two waves per SIMD on 256 registers: one step fits without spilling, two do not)
+#ifdef LDM_DKV_AHEAD
+      constexpr int AHQ = LDM_DKV_AHEAD;
+#else
+      constexpr int AHQ = DP == 128 ? 2 : 1;
+#endif
+      bf8_t qfr[T::NK], gfr[T::NK];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+      for (int kk = 0; kk < AHQ; ++kk) {
+        qfr[kk] = row_frag2<DP>(Qt, qbk * 32 + c, kk, half);
+        gfr[kk] = row_frag2<DP>(Gt, qbk * 32 + c, kk, half);
+      }
 #pragma unroll
       for (int kk = 0; kk < T::NK; ++kk) {
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Qt, qbk * 32 + c, kk, half), kf[kk], s0, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag2<DP>(Gt, qbk * 32 + c, kk, half), vf[kk], dpacc, 0, 0, 0);
+        if (kk + AHQ < T::NK) {
+          qfr[kk + AHQ] = row_frag2<DP>(Qt, qbk * 32 + c, kk + AHQ, half);
+          gfr[kk + AHQ] = row_frag2<DP>(Gt, qbk * 32 + c, kk + AHQ, half);
+        }
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[kk], kf[kk], s0, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[kk], vf[kk], dpacc, 0, 0, 0);
         if (qbk == 0 && kk < 2 * Lay<DP>::PW && more) {
           constexpr int PW = Lay<DP>::PW;
           if (kk < PW) qd.issue_one(kk, t + 1, S, a.ld, nb, wave);
@@ -1014,12 +1046,21 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       constexpr int NF = 2 * T::ND;
       s4_t glo[NF], ghi[NF], qlo[NF], qhi[NF];
       const unsigned gbo = go + qbk * 32 * Lay<DP>::PITCH, qbo = qo + qbk * 32 * Lay<DP>::PITCH;
-      tr_issue2(ta[0], gbo, glo[0], ghi[0]);
-      tr_issue2(ta[0], qbo, qlo[0], qhi[0]);
+#ifdef LDM_DKV_AHEAD2
+      constexpr int AH2 = LDM_DKV_AHEAD2;
+#else
+      constexpr int AH2 = 1;
+#endif
+#pragma unroll
+      for (int f = 0; f < AH2; ++f) {
+        const unsigned ro = (f / T::ND) * 16 * Lay<DP>::PITCH;
+        tr_issue2(ta[f % T::ND], gbo + ro, glo[f], ghi[f]);
+        tr_issue2(ta[f % T::ND], qbo + ro, qlo[f], qhi[f]);
+      }
       float p[16], ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pr = key_ok ? fast_exp2(fmaf(s0[r], LOG2E, sacc[r])) : 0.f;
+        const float pr = key_ok ? fast_exp2(s0[r] * LOG2E) : 0.f;
         if constexpr (DROP) {
           const unsigned qi = (unsigned)(t * 64 + qbk * 32 + acc_row(r) + 4 * half);
           const bool keep = ldm_drop_keep(ldm_drop_row(drop_bh, a.seed_hi, qi), (unsigned)key, a.drop_thresh);
@@ -1038,15 +1079,19 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       const bf8_t pf[2] = {pack8(p), pack8(p + 8)}, dsf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        if (f + 1 < NF) {
-          const unsigned ro = ((f + 1) / T::ND) * 16 * Lay<DP>::PITCH;
-          tr_issue2(ta[(f + 1) % T::ND], gbo + ro, glo[f + 1], ghi[f + 1]);
-          tr_issue2(ta[(f + 1) % T::ND], qbo + ro, qlo[f + 1], qhi[f + 1]);
+        if (f + AH2 < NF) {
+          const unsigned ro = ((f + AH2) / T::ND) * 16 * Lay<DP>::PITCH;
+          tr_issue2(ta[(f + AH2) % T::ND], gbo + ro, glo[f + AH2], ghi[f + AH2]);
+          tr_issue2(ta[(f + AH2) % T::ND], qbo + ro, qlo[f + AH2], qhi[f + AH2]);
         }
-        // in flight after the issue: fragment pairs f and f+1 (four reads each)
-        const bf8_t gf = (f + 1 < NF) ? tr_wait2<6>(glo[f], ghi[f]) : tr_wait2<2>(glo[f], ghi[f]);
+        // in flight after the issue: fragment pairs f .. min(f + AH2, NF - 1), four reads each (dO pair first)
+        const int yg = (NF - 1 - f) < AH2 ? (NF - 1 - f) : AH2;
+        static_assert(AH2 >= 1 && AH2 <= 3, "lgkmcnt is a 4-bit counter");
+        const bf8_t gf = yg == 3 ? tr_wait2<14>(glo[f], ghi[f]) : yg == 2 ? tr_wait2<10>(glo[f], ghi[f])
+                       : yg == 1 ? tr_wait2<6>(glo[f], ghi[f]) : tr_wait2<2>(glo[f], ghi[f]);
         dv[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, pf[f / T::ND], dv[f % T::ND], 0, 0, 0);
-        const bf8_t qf2 = (f + 1 < NF) ? tr_wait2<4>(qlo[f], qhi[f]) : tr_wait2<0>(qlo[f], qhi[f]);
+        const bf8_t qf2 = yg == 3 ? tr_wait2<12>(qlo[f], qhi[f]) : yg == 2 ? tr_wait2<8>(qlo[f], qhi[f])
+                        : yg == 1 ? tr_wait2<4>(qlo[f], qhi[f]) : tr_wait2<0>(qlo[f], qhi[f]);
         dk[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf2, dsf[f / T::ND], dk[f % T::ND], 0, 0, 0);
       }
     }
