@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     const char *Qt = smem + (t & 1) * BUF;
     const char *Gt = Qt + Lay<DP>::TILE;
     const float *lse_s = reinterpret_cast<const float *>(Qt + 2 * Lay<DP>::TILE);
-    const float *dlt_s = lse_s + 64;
+    // (delta follows lse: 64 floats on)
     const int lim = S - t * 64;   // query rows of this tile that exist
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1001,12 +1001,26 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     for (int qbk = 0; qbk < 2; ++qbk) {
       // the score accumulator starts at -lse and the dP accumulator at -delta: the products then leave
       // s - lse and dP - delta, with no register copy of the statistics beside them
+      // (read by asm: behind a read it can see, the compiler drains every LDS-DMA in flight, that is
+      // the next tile's statistics just requested and, before the second query block, its images too)
       f16_t s0, dpacc;
       [[maybe_unused]] float nd[16];
+      typedef float f4v_t __attribute__((ext_vector_type(4)));
+      f4v_t lq[4], dq4[4];
+      {
+        const unsigned so = lds_off(lse_s) + (qbk * 32 + 4 * half) * 4;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lq[r4]) : "v"(so), "n"(32 * r4));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dq4[r4]) : "v"(so), "n"(256 + 32 * r4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lq[0]), "+v"(lq[1]), "+v"(lq[2]), "+v"(lq[3]), "+v"(dq4[0]), "+v"(dq4[1]), "+v"(dq4[2]), "+v"(dq4[3]));
+      }
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 l4 = *reinterpret_cast<const float4 *>(lse_s + qbk * 32 + 8 * r4 + 4 * half);
-        const float4 d4 = *reinterpret_cast<const float4 *>(dlt_s + qbk * 32 + 8 * r4 + 4 * half);
+        const float4 l4 = make_float4(lq[r4][0], lq[r4][1], lq[r4][2], lq[r4][3]);
+        const float4 d4 = make_float4(dq4[r4][0], dq4[r4][1], dq4[r4][2], dq4[r4][3]);
         s0[4 * r4 + 0] = -l4.x; s0[4 * r4 + 1] = -l4.y;
         s0[4 * r4 + 2] = -l4.z; s0[4 * r4 + 3] = -l4.w;
         if constexpr (DROP) {   // the mask applies to dP alone: -delta is added after the products
