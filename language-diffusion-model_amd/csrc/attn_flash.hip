@@ -1394,10 +1394,11 @@ int flash_fwd_launch(const FArgs &a, hipStream_t s) {
 template <int DP, bool DROP>
 int flash2_fwd_launch_t(const FArgs &a, hipStream_t s) {
   constexpr int lds = 4 * Lay<DP>::TILE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  uint64_t dev_bit;
+  if (ldm_attr_pending(attr_done, &dev_bit)) {
     (void)hipFuncSetAttribute((const void *)flash2_fwd_k<DP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
   hipLaunchKernelGGL((flash2_fwd_k<DP, DROP>), grid, dim3(256), lds, s, a);
@@ -1423,11 +1424,12 @@ bool attn_dma_enabled() {
 template <int DP, bool DROP>
 int flash2_bwd_launch_t(const FArgs &a, hipStream_t s) {
   constexpr int lds_dq = 4 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  uint64_t dev_bit;
+  if (ldm_attr_pending(attr_done, &dev_bit)) {
     (void)hipFuncSetAttribute((const void *)flash2_bwd_dq_k<DP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
     (void)hipFuncSetAttribute((const void *)flash2_bwd_dkv_k<DP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-    attr_set = true;
+    attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   dim3 grid((unsigned)(ceil_div(a.S, 128) * a.H * a.B));
   hipLaunchKernelGGL((flash2_bwd_dq_k<DP, DROP>), grid, dim3(256), lds_dq, s, a);

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(BT) void ce_fwd_grad_k(T *logits, int64_t ld, int64
     for (int u = 0; u < NV; ++u) {
       if (u < nu) {
         const int c = threadIdx.x + u * BT;
-        v[u].load(row + (c < nv ? c : 0) * 8);
+        v[u].load_nt(row + (c < nv ? c : 0) * 8);   // read once, rewritten in place below: nothing to keep in cache
         if (c >= vlast) v[u].neg_inf_from(c == vlast ? jlast : 0);
       }
     }
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(BT) void ce_fwd_grad_k(T *logits, int64_t ld, int64
           for (int j = 0; j < 8; ++j)
             if (tj == j) o[j] -= winv;
         }
-        if (c < nv) Raw8<T>::store(row + (int64_t)c * 8, o);
+        if (c < nv) Raw8<T>::store_nt(row + (int64_t)c * 8, o);
       }
     __syncthreads();   // sm_xt is free for the next row
   }

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/ldm_hip.h"
@@ -84,6 +85,17 @@ template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
   uint4 u;
   __device__ __forceinline__ void load(const bf16_t *p) { u = *reinterpret_cast<const uint4 *>(p); }
+  // streaming forms: the line is not wanted in the caches after this access
+  __device__ __forceinline__ void load_nt(const bf16_t *p) {
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const u4_t t = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(p));
+    u = make_uint4(t[0], t[1], t[2], t[3]);
+  }
+  static __device__ __forceinline__ void store_nt(bf16_t *p, const float (&o)[8]) {
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    u4_t t = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    __builtin_nontemporal_store(t, reinterpret_cast<u4_t *>(p));
+  }
   // opaque use: values derived from the registers before this point are not kept alive past it
   // (a multi-pass kernel re-derives them from the 16 stored bytes instead of holding 8 floats)
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
@@ -118,6 +130,8 @@ template <> struct Raw8<float> {
     a = *reinterpret_cast<const float4 *>(p);
     b = *reinterpret_cast<const float4 *>(p + 4);
   }
+  __device__ __forceinline__ void load_nt(const float *p) { load(p); }
+  static __device__ __forceinline__ void store_nt(float *p, const float (&o)[8]) { store(p, o); }
   __device__ __forceinline__ void pin() {}
   __device__ __forceinline__ void neg_inf_from(int j0) {
     const float ninf = -__builtin_inff();
@@ -148,6 +162,17 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Per-kernel, per-device "attribute has been set" mask for launchers that raise a kernel's dynamic LDS limit:
+// hipFuncSetAttribute acts on the current device's copy of the kernel.  A thread that finds its device's
+// bit clear sets the attribute itself before launching (two racing threads both do; the call is
+// idempotent), so no launch can precede the attribute on its device.
+static inline bool ldm_attr_pending(std::atomic<uint64_t> &done, uint64_t *bit) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  *bit = 1ull << (dev & 63);
+  return (done.load(std::memory_order_acquire) & *bit) == 0;
 }
 
 static inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

@@ -235,9 +235,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w
     for (int i = 0; i < NV; ++i) {
       const int vi = lane + i * 64;
       if (vi < nvec) {
-        xv[i].load(x + r * d + vi * 8);
-        gv[i].load(dy + r * d + vi * 8);
-        if (RES) rv[i].load(dres + r * d + vi * 8);
+        // streaming accesses (-8 % alone, -4.5 % in the step): none of the four arrays is read again soon
+        xv[i].load_nt(x + r * d + vi * 8);
+        gv[i].load_nt(dy + r * d + vi * 8);
+        if (RES) rv[i].load_nt(dres + r * d + vi * 8);
       }
     }
     float dot = 0.f;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w
           o[j] = fmaf(rs, gv[i].get(j) * wv[i][j], -xv[i].get(j) * k);
           if (RES) o[j] += rv[i].get(j);
         }
-        Raw8<T>::store(dx + r * d + vi * 8, o);
+        Raw8<T>::store_nt(dx + r * d + vi * 8, o);
       }
     }
   }

@@ -272,12 +272,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_k(MArgs g) {
 
 template <bool A_KC, bool B_KC, typename TO, int EPI>
 int launch_mfma(const MArgs &g, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   const size_t lds = 4 * TILE_BYTES;
-  if (!attr_set) {
+  uint64_t dev_bit;
+  if (ldm_attr_pending(attr_done, &dev_bit)) {
     (void)hipFuncSetAttribute((const void *)gemm_mfma_k<A_KC, B_KC, TO, EPI>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * g.splits;
   hipLaunchKernelGGL((gemm_mfma_k<A_KC, B_KC, TO, EPI>), dim3((unsigned)nwg), dim3(256), lds, s, g);

@@ -1009,11 +1009,12 @@ template <bool A_KC, bool B_KC, int BN, typename TO, int EPI, int RES = 0>
 int launch256(const MArgs &g_in, hipStream_t s) {
   MArgs g = g_in;
   if (const int b = band_override(RES, EPI, g.K, g.N)) g.band_m = b;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  uint64_t dev_bit;
+  if (ldm_attr_pending(attr_done, &dev_bit)) {
     (void)hipFuncSetAttribute((const void *)gemm256_k<A_KC, B_KC, BN, TO, EPI, RES>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
+    attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   const int64_t items = (int64_t)g.tiles_m * g.tiles_n * g.splits;
   const int64_t nwg = items < num_cus() ? items : num_cus();   // persistent: one workgroup per CU
