@@ -226,9 +226,12 @@ __device__ __forceinline__ void store_tile_lds(char *wlds, bf16_t *dst, int64_t 
   for (int i = 0; i < (NPIECE + 63) / 64; ++i) {
     const int idx = lane + 64 * i;
     const int row = idx / T::CPR, piece = idx - row * T::CPR;
-    if (idx < NPIECE && row < rows_ok && piece * 8 < hd)
-      *reinterpret_cast<uint4 *>(dst + (int64_t)row * ld + piece * 8) =
-          *reinterpret_cast<const uint4 *>(wlds + row * T::RSTR + piece * 16);
+    if (idx < NPIECE && row < rows_ok && piece * 8 < hd) {
+      typedef unsigned u4n_t __attribute__((ext_vector_type(4)));
+      const u4n_t v = *reinterpret_cast<const u4n_t *>(wlds + row * T::RSTR + piece * 16);
+      // (streamed: the consumer is a GEMM several hundred MB later; -1 % on the backward in the step)
+      __builtin_nontemporal_store(v, reinterpret_cast<u4n_t *>(dst + (int64_t)row * ld + piece * 8));
+    }
   }
 }
 
