@@ -44,20 +44,25 @@ def test_step_golden(name):
     params = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
     ids = torch.from_numpy(g["input_ids"])
     att = torch.from_numpy(g["attention_mask"])
+    # fp32 must reproduce the recorded reference run to rounding.  The bf16-autocast run goes through
+    # oneDNN's bf16 matmul, whose accumulation order depends on the host CPU (AVX512-BF16 / AMX or not):
+    # a rounding of one bf16 product that flips moves the small q/k gradients by a few 1e-3, so that mode
+    # is held to bf16's own resolution, not to fp32's.
     for mode in ("fp32", "bf16"):
+        ltol, gtol = (1e-6, 2e-6) if mode == "fp32" else (1e-4, 1e-2)
         loss, grads, masked, mask, logits = so.step_loss_and_grads(
             params, cfg, ids, att, float(g["t"][0]), torch.from_numpy(g["draw"]), autocast_bf16=(mode == "bf16"))
         assert np.array_equal(masked.numpy(), g["masked_input_ids"])
         assert np.array_equal(mask.numpy(), g["mask_indices"])
-        assert rel_err(loss, g[f"loss_{mode}"]) < 1e-6
+        assert rel_err(loss, g[f"loss_{mode}"]) < ltol
         if mode == "fp32":
             assert rel_err(logits, g["logits_fp32"]) < 1e-6
         for k, v in grads.items():
             ref = g[f"grad_{mode}/{k}"]
             if "k_proj.bias" in k:
-                assert float(np.abs(v.numpy() - ref).max()) < 1e-6
+                assert float(np.abs(v.numpy() - ref).max()) < gtol
             else:
-                assert rel_err(v, ref) < 2e-6, (mode, k)
+                assert rel_err(v, ref) < gtol, (mode, k)
 
 
 def test_sampling_golden():
