@@ -14,6 +14,10 @@ for n, k in [(3 * d, d), (d, d), (2 * F, d), (d, F), (V, d)]:
     shapes.append(("fwd", 0, 1, T, n, k))
     shapes.append(("dx", 0, 0, T, k, n))
     shapes.append(("dw", 1, 0, n, k, T))
+if os.environ.get("CUBE"):      # calibration: square problems (A [M,K], B [N,K], both K-contiguous), e.g. CUBE=4096,8192
+    shapes = [("fwd", 0, 1, int(n), int(n), int(n)) for n in os.environ["CUBE"].split(",")]
+    shapes += [("dx", 0, 0, int(n), int(n), int(n)) for n in os.environ["CUBE"].split(",")]
+    shapes += [("dw", 1, 0, int(n), int(n), int(n)) for n in os.environ["CUBE"].split(",")]
 torch.manual_seed(0)
 # clocks and power state settle over the first tens of milliseconds of load: warm up before the first shape
 _w = torch.randn(8192, 8192, device=dev).bfloat16()

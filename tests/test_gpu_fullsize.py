@@ -76,7 +76,12 @@ def _compare(model, og, ol, loss, tol, label, ref_noise=None):
             # (where the residue is that of bf16-rounded dK rows) a fifth of it.
             scale = float(og[n.replace("k_proj", "q_proj")].abs().max())
             bound = tol * scale if tol < 1e-3 else 0.2 * scale
-            assert float((p.grad.float().cpu() - og[n]).abs().max()) < bound, n
+            # the oracle's own value is such a residue too: in the 16-layer, 2048-wide model it is as large as
+            # the query-bias gradient itself (2e-6 against 1.6e-6 in the last layer, fp32 on the host), so the
+            # bound is never tighter than a few times what the oracle holds
+            bound = max(bound, 4.0 * float(og[n].abs().max()))
+            got = float((p.grad.float().cpu() - og[n]).abs().max())
+            assert got < bound, (label, n, got, bound, scale, float(og[n].abs().max()))
             continue
         e = rel_err(p.grad, og[n])
         if ref_noise is not None:
@@ -161,6 +166,36 @@ def test_one_1b_layer_at_seq_4096_matches_oracle(dev):
         loss = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([t]))
         loss.backward()
         _compare(model, og, ol, loss.item(), tol, f"1b-layer/{mode}")
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_1b_model_full_depth_matches_oracle(dev):
+    """The ~1B model at FULL depth (16 layers, d=2048, 16 heads of 128, ff=5632, V=32000), B=2, S=1024,
+    one sequence with a padded tail: fp32 and bf16 (fused head) against the fp32 oracle.  The sequence is
+    shorter than the 4096 of the one-layer test above so that the oracle's two host runs (fp32, and the
+    bf16-autocast run that gives the per-tensor yardstick) stay within a minute."""
+    from oracle import step_oracle as so
+    ocfg = so.OracleConfig(vocab_size=32000, d_model=2048, nhead=16, num_layers=16, dim_feedforward=5632)
+    params = so.init_params(ocfg, seed=17)
+    S = 1024
+    ids, att = so.synthetic_batch(2, S, 32000, seed=18, ragged=False, dirty=True)
+    att[1, 700:] = 0
+    ids[1, 699] = 102
+    ids[1, 700:] = 0
+    draw = torch.rand(2, S, generator=torch.Generator().manual_seed(19))
+    t = 0.6
+    torch.set_num_threads(16)
+    ol, og, _, _, _ = so.step_loss_and_grads(params, ocfg, ids, att, t, draw)
+    _, og16, _, _, _ = so.step_loss_and_grads(params, ocfg, ids, att, t, draw, autocast_bf16=True)
+    noise = {n: rel_err(og16[n], og[n]) for n in og}
+    for mode, dtype, tol in (("fp32", torch.float32, 1e-5), ("bf16", torch.bfloat16, 2e-2)):
+        model = _model_from(params, ocfg, dev, dtype, S)
+        model.masking_strategy = _InjectedDraw(model.masking_strategy, draw.to(dev))
+        loss = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([t]))
+        loss.backward()
+        _compare(model, og, ol, loss.item(), tol, f"1b-full-depth/{mode}",
+                 ref_noise=noise if mode == "bf16" else None)
         del model
         torch.cuda.empty_cache()
 
