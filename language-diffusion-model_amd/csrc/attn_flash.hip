@@ -300,29 +300,37 @@ __device__ __forceinline__ void store_rounding_residual(const FArgs &a, const f1
 }
 
 // This lane's part of rowsum(o_lo[row] * dO[row]) (see FArgs::o_lo) against the dO fragments the lane already
-// holds (dof[kk] = positions 16 kk + 8 half + 0..7); the caller's cross-half add completes the row.
+// holds (dof[kk] = positions 16 kk + 8 half + 0..7); the caller's cross-half add completes the row.  In two
+// steps, so that the caller can request the bytes together with its other prologue loads (one trip to
+// memory instead of one after the other).
 template <int DP>
-__device__ __forceinline__ float delta_residual(const FArgs &a, const Blk &blk, int wave, int lane,
-                                                const bf8_t (&dof)[AT<DP>::NK]) {
-  float acc = 0.f;
+__device__ __forceinline__ void delta_residual_load(const FArgs &a, const Blk &blk, int wave, int lane,
+                                                    uint4 (&lo)[AT<DP>::ND]) {
+#pragma unroll
+  for (int db = 0; db < AT<DP>::ND; ++db) lo[db] = make_uint4(0u, 0u, 0u, 0u);   // fp8 zero
   if (a.o_lo_in) {
     const int nblk = (a.S + 127) / 128;
     const unsigned char *slot = reinterpret_cast<const unsigned char *>(a.o_lo_in) +
                                 (((((int64_t)blk.b * a.H + blk.head) * nblk + blk.blk) * 4 + wave) * 64 + lane) * (DP / 2);
 #pragma unroll
-    for (int db = 0; db < AT<DP>::ND; ++db) {
-      const uint4 lo = *reinterpret_cast<const uint4 *>(slot + db * 16);
-      const unsigned lw[4] = {lo.x, lo.y, lo.z, lo.w};
+    for (int db = 0; db < AT<DP>::ND; ++db) lo[db] = *reinterpret_cast<const uint4 *>(slot + db * 16);
+  }
+}
+template <int DP>
+__device__ __forceinline__ float delta_residual(const uint4 (&lo)[AT<DP>::ND], const bf8_t (&dof)[AT<DP>::NK]) {
+  float acc = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = 2 * db + (q >> 1), j0 = 4 * (q & 1);
-        const auto r01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lw[q], false);
-        const auto r23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lw[q], true);
-        acc = fmaf(r01[0], (float)dof[kk][j0 + 0], acc);
-        acc = fmaf(r01[1], (float)dof[kk][j0 + 1], acc);
-        acc = fmaf(r23[0], (float)dof[kk][j0 + 2], acc);
-        acc = fmaf(r23[1], (float)dof[kk][j0 + 3], acc);
-      }
+  for (int db = 0; db < AT<DP>::ND; ++db) {
+    const unsigned lw[4] = {lo[db].x, lo[db].y, lo[db].z, lo[db].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 2 * db + (q >> 1), j0 = 4 * (q & 1);
+      const auto r01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lw[q], false);
+      const auto r23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lw[q], true);
+      acc = fmaf(r01[0], (float)dof[kk][j0 + 0], acc);
+      acc = fmaf(r01[1], (float)dof[kk][j0 + 1], acc);
+      acc = fmaf(r23[0], (float)dof[kk][j0 + 2], acc);
+      acc = fmaf(r23[1], (float)dof[kk][j0 + 3], acc);
     }
   }
   return acc * OLO_INV;
@@ -537,6 +545,48 @@ struct Lay {
 template <int DP>
 struct TileDma {
   using L = Lay<DP>;
+  const char *base;         // wave-uniform: row 0 of tile 0 (scalar registers)
+  unsigned off[L::PW];      // byte offset of this lane's source in tile 0, piece i (32 bits: 64 rows of one sequence)
+  int64_t step;             // 64 rows, bytes
+  static __device__ __forceinline__ int row_of(int i, int wave, int lane) { return ((wave * L::PW + i) * 64 + lane) / L::CPR; }
+  __device__ __forceinline__ void init(const bf16_t *b, int64_t ld, int wave, int lane) {
+    base = reinterpret_cast<const char *>(b);
+    step = 128 * ld;
+#pragma unroll
+    for (int i = 0; i < L::PW; ++i) {
+      const int cidx = (wave * L::PW + i) * 64 + lane;   // chunk slot of this lane in the image
+      const int row = cidx / L::CPR, slot = cidx % L::CPR;
+      off[i] = (unsigned)(row * (int)(2 * ld) + L::pos(slot, row) * 16);   // pos() is its own inverse
+    }
+  }
+  // piece i of tile t -> image `img`; rows >= S re-read row S-1 (finite values; masked later)
+  __device__ __forceinline__ void issue_one(int i, int t, int S, int64_t ld, char *img, int wave) const {
+    const int lim = S - 64 * t;            // wave-uniform
+    int64_t toff = (int64_t)t * step;      // a scalar product: the tile's base stays in scalar registers
+    asm volatile("" : "+s"(toff));
+    const char *tb = base + toff;
+    unsigned o = off[i];
+    if (__builtin_expect(lim < 64, 0)) {
+      // the last, partial tile only.  The empty asm keeps this a branch: as a select the clamp costs every
+      // tile of every piece two quarter-rate integer multiplies and a multiply-add per lane
+      // (about a third of the vector work of a forward tile at head dim 96).
+      asm volatile("" : "+v"(o));
+      const int row0 = row_of(i, wave, (int)(threadIdx.x & 63));
+      o -= (unsigned)((row0 >= lim ? row0 - (lim - 1) : 0) * (int)(2 * ld));
+    }
+    __builtin_amdgcn_global_load_lds(GLB_PTR2(tb + o), LDS_PTR2(img + (wave * L::PW + i) * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void issue(int t, int S, int64_t ld, char *img, int wave) const {
+#pragma unroll
+    for (int i = 0; i < L::PW; ++i) issue_one(i, t, S, ld, img, wave);
+  }
+};
+
+// The same with one 64-bit source pointer per piece: the dK/dV kernel at head dim 96 sits at 256 registers and
+// the register allocator spills with the form above but not with this one.
+template <int DP>
+struct TileDmaP {
+  using L = Lay<DP>;
   const bf16_t *p[L::PW];   // source of this lane in tile 0, piece i
   int row0[L::PW];          // its tile-relative row
   int64_t step;             // 64 rows
@@ -597,6 +647,13 @@ __device__ __forceinline__ void tr_issue2(const TrAddr<DP> &ta, unsigned off, s4
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ta.a0 + off));
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ta.a1 + off));
 }
+// The same with the image / row-block offset as the instruction's immediate: `b0`, `b1` = the two per-lane
+// addresses with the image's base already added (once per tile), `imm` a constant once the loops around
+// the call are unrolled.  One vector add per read less than tr_issue2.
+__device__ __forceinline__ void tr_issue2o(unsigned b0, unsigned b1, int imm, s4_t &lo, s4_t &hi) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(b0), "n"(imm));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(b1), "n"(imm));
+}
 template <int N>
 __device__ __forceinline__ bf8_t tr_wait2(s4_t &lo, s4_t &hi) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
@@ -609,6 +666,10 @@ __device__ __forceinline__ unsigned lds_off(const void *p) {
 
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_entry; ASTAMP(t_entry);
+  const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -624,7 +685,12 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
 
   TrAddr<DP> vta[T::ND];
 #pragma unroll
-  for (int i = 0; i < T::ND; ++i) vta[i].init(i, lane);
+  for (int i = 0; i < T::ND; ++i) {
+    // absolute addresses into the V image of the CURRENT buffer; they move to the other buffer at the end
+    // of every tile
+    vta[i].init(i, lane);
+    vta[i].a0 += lds_off(smem) + Lay<DP>::TILE; vta[i].a1 += lds_off(smem) + Lay<DP>::TILE;
+  }
   TileDma<DP> kd, vd;
   kd.init(kb, a.ld, wave, lane);
   vd.init(vb, a.ld, wave, lane);
@@ -740,11 +806,10 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     ASTAMP(s3);
     {
       constexpr int NF = 4 * T::ND;
-      const unsigned vo = lds_off(Vt);
       s4_t lo[NF], hi[NF];
       bf8_t pf[4];
-      tr_issue2(vta[0], vo, lo[0], hi[0]);
-      tr_issue2(vta[1 % T::ND], vo + (1 / T::ND) * 16 * Lay<DP>::PITCH, lo[1], hi[1]);
+      tr_issue2o(vta[0].a0, vta[0].a1, 0, lo[0], hi[0]);
+      tr_issue2o(vta[1 % T::ND].a0, vta[1 % T::ND].a1, (1 / T::ND) * 16 * Lay<DP>::PITCH, lo[1], hi[1]);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         float tmp[8];
@@ -754,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        if (f + 2 < NF) tr_issue2(vta[(f + 2) % T::ND], vo + ((f + 2) / T::ND) * 16 * Lay<DP>::PITCH, lo[f + 2], hi[f + 2]);
+        if (f + 2 < NF) tr_issue2o(vta[(f + 2) % T::ND].a0, vta[(f + 2) % T::ND].a1, ((f + 2) / T::ND) * 16 * Lay<DP>::PITCH, lo[f + 2], hi[f + 2]);
         // reads in flight after this issue: fragments f .. min(f+2, NF-1), two each
         const bf8_t vf = (f + 2 < NF) ? tr_wait2<4>(lo[f], hi[f]) : (f + 1 < NF) ? tr_wait2<2>(lo[f], hi[f]) : tr_wait2<0>(lo[f], hi[f]);
         oacc[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[f / T::ND], oacc[f % T::ND], 0, 0, 0);
@@ -764,7 +829,13 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     ASTAMP(s4);
     ta[0] += s1 - s0; ta[1] += s2 - s1; ta[2] += s3 - s2; ta[3] += s4 - s3; ta[5] += 1;
 #endif
+    const int flip = (t & 1) ? -2 * Lay<DP>::TILE : 2 * Lay<DP>::TILE;
+#pragma unroll
+    for (int i = 0; i < T::ND; ++i) { vta[i].a0 += flip; vta[i].a1 += flip; }
   }
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_loop1; ASTAMP(t_loop1);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // every wave is done with the tiles: the epilogue re-uses the LDS
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -785,6 +856,16 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     for (int i = 0; i < 6; ++i) a.timing[i] = ta[i];
     a.timing[6] = tk1 - tk0;
   }
+  // a workgroup from the middle of the grid: cycles entry -> loop, loop, loop -> stores issued; stores
+  // drained; and its lifetime in 10-ns ticks
+  if (a.timing && tid == 0 && blockIdx.x == gridDim.x / 2 + 8) {
+    unsigned long long te; ASTAMP(te);
+    a.timing[16] = tk0 - t_entry; a.timing[17] = t_loop1 - tk0; a.timing[18] = te - t_loop1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long td; ASTAMP(td);
+    a.timing[19] = td - te;
+    a.timing[20] = __builtin_amdgcn_s_memrealtime() - r_entry;
+  }
   if (a.timing && lane == 0 && blockIdx.x == 8) { a.timing[8 + wave] = tb; a.timing[12 + wave] = ta[4]; }
 #endif
 }
@@ -792,6 +873,10 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
 // --------------------------------------------------------------------------- dQ, LDS-DMA tiles
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs a) {
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_entry; ASTAMP(t_entry);
+  const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   using T = AT<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -809,7 +894,12 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 
   TrAddr<DP> kta[T::ND];
 #pragma unroll
-  for (int i = 0; i < T::ND; ++i) kta[i].init(i, lane);
+  for (int i = 0; i < T::ND; ++i) {
+    // absolute addresses into the K image of the CURRENT buffer; they move to the other buffer at the end
+    // of every tile
+    kta[i].init(i, lane);
+    kta[i].a0 += lds_off(smem); kta[i].a1 += lds_off(smem);
+  }
   TileDma<DP> kd, vd;
   kd.init(kb, a.ld, wave, lane);
   vd.init(vb, a.ld, wave, lane);
@@ -818,20 +908,29 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 
   bf8_t qf[T::NK], dof[T::NK];
   const bf16_t *ob = a.o_in + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  float dsum = 0.f;
+  // every prologue load is requested before the first of them is used: one trip to memory for Q, dO, O, the
+  // rounding residual of O and the row's log-sum-exp (requested one group after the other, each group behind
+  // the use of the one before, the prologue was three trips: a quarter of the workgroup's lifetime at S = 512)
+  const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
+  uint4 olo[T::ND];
+  delta_residual_load<DP>(a, blk, wave, lane, olo);
+  const float lse_row = a.lse_in[stat];
+  bf8_t ofr[T::NK];
 #pragma unroll
   for (int kk = 0; kk < T::NK; ++kk) {
     qf[kk] = global_frag(qb, a.ld, qc, true, kk, half, hd);
     dof[kk] = global_frag(dob, a.ld_o, qc, true, kk, half, hd);
-    const bf8_t of = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
+    ofr[kk] = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
   }
-  dsum += delta_residual<DP>(a, blk, wave, lane, dof);
+  float dsum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum = fmaf((float)ofr[kk][j], (float)dof[kk][j], dsum);
+  dsum += delta_residual<DP>(olo, dof);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
-  const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
-  const float nlse = -a.lse_in[stat] * LOG2E;
+  const float nlse = -lse_row * LOG2E;
   if (half == 0 && q < S) a.delta[stat] = dlt;
 
   f16_t dq[T::ND];
@@ -840,6 +939,9 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_loop0; ASTAMP(t_loop0);
+#endif
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
     const int k0 = t * 64;
@@ -847,13 +949,14 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
     const char *Vt = Kt + Lay<DP>::TILE;
     bool kok = (k0 + lane) < S;
     if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
-    const unsigned long long vs = __ballot(kok) >> (4 * half);
+    const unsigned long long bal = __ballot(kok);
+    const bool all_valid = bal == ~0ull;          // wave-uniform: the common tile has no padded key
+    const unsigned long long vs = bal >> (4 * half);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the next tile's LDS-DMA goes out one instruction at a time between the first MFMAs
     const bool more = t + 1 < nt;
     char *nb = smem + ((t + 1) & 1) * 2 * Lay<DP>::TILE;
-    const unsigned ko = lds_off(Kt);
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk) {
       f16_t sacc, dpacc;
@@ -887,27 +990,40 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
       }
       constexpr int NF = 2 * T::ND;
       s4_t lo[NF], hi[NF];
-      const unsigned kbo = ko + kbk * 32 * Lay<DP>::PITCH;
+      const int kbo = kbk * 32 * Lay<DP>::PITCH;   // (immediate offsets from here on)
       // all transposed K fragments of this key block are requested before the exponentials:
       // the LDS round trips overlap that VALU work instead of the MFMA chain below
       constexpr int AH = DP == 96 ? NF : 4;
 #pragma unroll
       for (int f = 0; f < AH; ++f)
-        tr_issue2(kta[f % T::ND], kbo + (f / T::ND) * 16 * Lay<DP>::PITCH, lo[f], hi[f]);
+        tr_issue2o(kta[f % T::ND].a0, kta[f % T::ND].a1, kbo + (f / T::ND) * 16 * Lay<DP>::PITCH, lo[f], hi[f]);
       float ds[16];
+      // (the validity test is three vector instructions per element: a third of the tile's vector work, so the
+      // tile without a padded key -- every tile of an unpadded batch -- takes a branch around it)
+      if (all_valid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = (vs >> (kbk * 32 + acc_row(r))) & 1ull;
-        const float p = ok ? fast_exp2(fmaf(sacc[r], LOG2E, nlse)) : 0.f;
-        if constexpr (DROP)
-          ds[r] = p * ((ldm_drop_keep(drop_row, (unsigned)(k0 + 4 * half + kbk * 32 + acc_row(r)), a.drop_thresh) ? dpacc[r] * a.drop_inv : 0.f) - dlt);
-        else
-          ds[r] = p * (dpacc[r] - dlt);
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(fmaf(sacc[r], LOG2E, nlse));
+          if constexpr (DROP)
+            ds[r] = p * ((ldm_drop_keep(drop_row, (unsigned)(k0 + 4 * half + kbk * 32 + acc_row(r)), a.drop_thresh) ? dpacc[r] * a.drop_inv : 0.f) - dlt);
+          else
+            ds[r] = p * (dpacc[r] - dlt);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = (vs >> (kbk * 32 + acc_row(r))) & 1ull;
+          const float p = ok ? fast_exp2(fmaf(sacc[r], LOG2E, nlse)) : 0.f;
+          if constexpr (DROP)
+            ds[r] = p * ((ldm_drop_keep(drop_row, (unsigned)(k0 + 4 * half + kbk * 32 + acc_row(r)), a.drop_thresh) ? dpacc[r] * a.drop_inv : 0.f) - dlt);
+          else
+            ds[r] = p * (dpacc[r] - dlt);
+        }
       }
       const bf8_t dsf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        if (f + AH < NF) tr_issue2(kta[(f + AH) % T::ND], kbo + ((f + AH) / T::ND) * 16 * Lay<DP>::PITCH, lo[f + AH], hi[f + AH]);
+        if (f + AH < NF) tr_issue2o(kta[(f + AH) % T::ND].a0, kta[(f + AH) % T::ND].a1, kbo + ((f + AH) / T::ND) * 16 * Lay<DP>::PITCH, lo[f + AH], hi[f + AH]);
         // reads in flight now: fragments f .. min(f + AH, NF - 1), two each
         constexpr int LAST = NF - 1;
         const int ahead = (f + AH < NF ? f + AH : LAST) - f;
@@ -918,7 +1034,13 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
         dq[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf[f / T::ND], dq[f % T::ND], 0, 0, 0);
       }
     }
+    const int flip = (t & 1) ? -2 * Lay<DP>::TILE : 2 * Lay<DP>::TILE;
+#pragma unroll
+    for (int i = 0; i < T::ND; ++i) { kta[i].a0 += flip; kta[i].a1 += flip; }
   }
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_loop1; ASTAMP(t_loop1);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
@@ -930,6 +1052,16 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
     else if (q < S)
       store_rows<DP>(a.dqkv + ((int64_t)b * S + q) * a.ld + (int64_t)head * hd, dq, 1.0f, half, hd);
   }
+#ifdef LDM_ATTN_TIMING
+  if (a.timing && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 8) {
+    unsigned long long te; ASTAMP(te);
+    a.timing[24] = t_loop0 - t_entry; a.timing[25] = t_loop1 - t_loop0; a.timing[26] = te - t_loop1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long td; ASTAMP(td);
+    a.timing[27] = td - te;
+    a.timing[28] = __builtin_amdgcn_s_memrealtime() - r_entry;
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------- dK, dV, LDS-DMA tiles
@@ -937,6 +1069,10 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 // instruction of wave 0 / wave 1) land in one of two buffers; one barrier per tile.
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs a) {
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_entry; ASTAMP(t_entry);
+  const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   using T = AT<DP>;
   constexpr int BUF = 2 * Lay<DP>::TILE + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q image, dO image, lse[64], delta[64])
@@ -951,16 +1087,19 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
   const int key = blk.blk * 128 + wave * 32 + c;
-  bool key_ok = key < S;
-  if (key_ok && a.key_valid) key_ok = a.key_valid[(int64_t)b * S + key] != 0;
   const int keyc = key < S ? key : S - 1;
   const unsigned drop_bh = DROP ? ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)) : 0u;
   const int64_t stat0 = ((int64_t)b * a.H + head) * S;
 
   TrAddr<DP> ta[T::ND];
 #pragma unroll
-  for (int i = 0; i < T::ND; ++i) ta[i].init(i, lane);
-  TileDma<DP> qd, gd;
+  for (int i = 0; i < T::ND; ++i) {
+    // absolute addresses into the Q image of the CURRENT buffer (the dO image is one image further on);
+    // they move to the other buffer at the end of every tile
+    ta[i].init(i, lane);
+    ta[i].a0 += lds_off(smem); ta[i].a1 += lds_off(smem);
+  }
+  TileDmaP<DP> qd, gd;
   qd.init(qb, a.ld, wave, lane);
   gd.init(dob, a.ld_o, wave, lane);
   auto issue_stats = [&](int t, char *buf) {
@@ -980,12 +1119,25 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     kf[kk] = global_frag(kb, a.ld, keyc, key < S, kk, half, hd);
     vf[kk] = global_frag(vb, a.ld, keyc, key < S, kk, half, hd);
   }
+  // the key's validity byte travels with the loads above (asked for first and compared at once, it was a
+  // trip to memory of its own before anything else had been requested)
+  unsigned key_byte = 1u;
+  if (key < S && a.key_valid) key_byte = a.key_valid[(int64_t)b * S + key];
+  asm volatile("" : "+v"(key_byte));
+  const bool key_ok = key < S && key_byte != 0;
+  // a padded key starts its score accumulator at -infinity: its probabilities come out of the exponential as
+  // zeros, with no select per element
+  // (the dropout variant sits at the register limit and keeps the select: key_bias is a constant there)
+  const float key_bias = (DROP || key_ok) ? 0.f : -INFINITY;
   f16_t dk[T::ND], dv[T::ND];
 #pragma unroll
   for (int i = 0; i < T::ND; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_loop0; ASTAMP(t_loop0);
+#endif
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
     const char *Qt = smem + (t & 1) * BUF;
@@ -999,7 +1151,6 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     const bool more = t + 1 < nt;
     char *nb = smem + ((t + 1) & 1) * BUF;
     if (more) issue_stats(t + 1, nb);
-    const unsigned qo = lds_off(Qt), go = lds_off(Gt);
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
       // the score accumulator starts at -lse and the dP accumulator at -delta: the products then leave
@@ -1024,8 +1175,8 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       for (int r4 = 0; r4 < 4; ++r4) {
         const float4 l4 = make_float4(lq[r4][0], lq[r4][1], lq[r4][2], lq[r4][3]);
         const float4 d4 = make_float4(dq4[r4][0], dq4[r4][1], dq4[r4][2], dq4[r4][3]);
-        s0[4 * r4 + 0] = -l4.x; s0[4 * r4 + 1] = -l4.y;
-        s0[4 * r4 + 2] = -l4.z; s0[4 * r4 + 3] = -l4.w;
+        s0[4 * r4 + 0] = key_bias - l4.x; s0[4 * r4 + 1] = key_bias - l4.y;
+        s0[4 * r4 + 2] = key_bias - l4.z; s0[4 * r4 + 3] = key_bias - l4.w;
         if constexpr (DROP) {   // the mask applies to dP alone: -delta is added after the products
           nd[4 * r4 + 0] = -d4.x; nd[4 * r4 + 1] = -d4.y; nd[4 * r4 + 2] = -d4.z; nd[4 * r4 + 3] = -d4.w;
           dpacc[4 * r4 + 0] = 0.f; dpacc[4 * r4 + 1] = 0.f; dpacc[4 * r4 + 2] = 0.f; dpacc[4 * r4 + 3] = 0.f;
@@ -1062,7 +1213,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       }
       constexpr int NF = 2 * T::ND;
       s4_t glo[NF], ghi[NF], qlo[NF], qhi[NF];
-      const unsigned gbo = go + qbk * 32 * Lay<DP>::PITCH, qbo = qo + qbk * 32 * Lay<DP>::PITCH;
+      const int qbo = qbk * 32 * Lay<DP>::PITCH, gbo = Lay<DP>::TILE + qbo;   // immediates
 #ifdef LDM_DKV_AHEAD2
       constexpr int AH2 = LDM_DKV_AHEAD2;
 #else
@@ -1070,14 +1221,14 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 #endif
 #pragma unroll
       for (int f = 0; f < AH2; ++f) {
-        const unsigned ro = (f / T::ND) * 16 * Lay<DP>::PITCH;
-        tr_issue2(ta[f % T::ND], gbo + ro, glo[f], ghi[f]);
-        tr_issue2(ta[f % T::ND], qbo + ro, qlo[f], qhi[f]);
+        const int ro = (f / T::ND) * 16 * Lay<DP>::PITCH;
+        tr_issue2o(ta[f % T::ND].a0, ta[f % T::ND].a1, gbo + ro, glo[f], ghi[f]);
+        tr_issue2o(ta[f % T::ND].a0, ta[f % T::ND].a1, qbo + ro, qlo[f], qhi[f]);
       }
       float p[16], ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pr = key_ok ? fast_exp2(s0[r] * LOG2E) : 0.f;
+        const float pr = (!DROP || key_ok) ? fast_exp2(s0[r] * LOG2E) : 0.f;
         if constexpr (DROP) {
           const unsigned qi = (unsigned)(t * 64 + qbk * 32 + acc_row(r) + 4 * half);
           const bool keep = ldm_drop_keep(ldm_drop_row(drop_bh, a.seed_hi, qi), (unsigned)key, a.drop_thresh);
@@ -1097,9 +1248,9 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         if (f + AH2 < NF) {
-          const unsigned ro = ((f + AH2) / T::ND) * 16 * Lay<DP>::PITCH;
-          tr_issue2(ta[(f + AH2) % T::ND], gbo + ro, glo[f + AH2], ghi[f + AH2]);
-          tr_issue2(ta[(f + AH2) % T::ND], qbo + ro, qlo[f + AH2], qhi[f + AH2]);
+          const int ro = ((f + AH2) / T::ND) * 16 * Lay<DP>::PITCH;
+          tr_issue2o(ta[(f + AH2) % T::ND].a0, ta[(f + AH2) % T::ND].a1, gbo + ro, glo[f + AH2], ghi[f + AH2]);
+          tr_issue2o(ta[(f + AH2) % T::ND].a0, ta[(f + AH2) % T::ND].a1, qbo + ro, qlo[f + AH2], qhi[f + AH2]);
         }
         // in flight after the issue: fragment pairs f .. min(f + AH2, NF - 1), four reads each (dO pair first)
         const int yg = (NF - 1 - f) < AH2 ? (NF - 1 - f) : AH2;
@@ -1112,7 +1263,13 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
         dk[f % T::ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf2, dsf[f / T::ND], dk[f % T::ND], 0, 0, 0);
       }
     }
+    const int flip = (t & 1) ? -BUF : BUF;
+#pragma unroll
+    for (int i = 0; i < T::ND; ++i) { ta[i].a0 += flip; ta[i].a1 += flip; }
   }
+#ifdef LDM_ATTN_TIMING
+  unsigned long long t_loop1; ASTAMP(t_loop1);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
@@ -1129,6 +1286,16 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       store_rows<DP>(row + 2 * D, dv, 1.0f, half, hd);
     }
   }
+#ifdef LDM_ATTN_TIMING
+  if (a.timing && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 8) {
+    unsigned long long te; ASTAMP(te);
+    a.timing[32] = t_loop0 - t_entry; a.timing[33] = t_loop1 - t_loop0; a.timing[34] = te - t_loop1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long td; ASTAMP(td);
+    a.timing[35] = td - te;
+    a.timing[36] = __builtin_amdgcn_s_memrealtime() - r_entry;
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------- dQ
@@ -1154,20 +1321,29 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_k(FArgs a) {
   // delta = rowsum(dO * O): each query row is split over the two half-lanes, so the row sum
   // is one cross-half exchange; it is also published for the dK/dV kernel that runs next.
   const bf16_t *ob = a.o_in + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  float dsum = 0.f;
+  // every prologue load is requested before the first of them is used: one trip to memory for Q, dO, O, the
+  // rounding residual of O and the row's log-sum-exp (requested one group after the other, each group behind
+  // the use of the one before, the prologue was three trips: a quarter of the workgroup's lifetime at S = 512)
+  const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
+  uint4 olo[T::ND];
+  delta_residual_load<DP>(a, blk, wave, lane, olo);
+  const float lse_row = a.lse_in[stat];
+  bf8_t ofr[T::NK];
 #pragma unroll
   for (int kk = 0; kk < T::NK; ++kk) {
     qf[kk] = global_frag(qb, a.ld, qc, true, kk, half, hd);
     dof[kk] = global_frag(dob, a.ld_o, qc, true, kk, half, hd);
-    const bf8_t of = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
+    ofr[kk] = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
   }
-  dsum += delta_residual<DP>(a, blk, wave, lane, dof);
+  float dsum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < T::NK; ++kk)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum = fmaf((float)ofr[kk][j], (float)dof[kk][j], dsum);
+  dsum += delta_residual<DP>(olo, dof);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
-  const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
-  const float nlse = -a.lse_in[stat] * LOG2E;
+  const float nlse = -lse_row * LOG2E;
   if (half == 0 && q < S) a.delta[stat] = dlt;
 
   f16_t dq[T::ND];
@@ -1512,6 +1688,9 @@ int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
   a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_scale = rope_scale;
   a.qkv = qkv; a.ld = ld; a.key_valid = key_valid; a.B = (int)B; a.H = (int)H; a.S = (int)S; a.hd = (int)hd;
   a.o_in = o; a.dout = dout; a.ld_o = ld_o; a.lse_in = lse; a.dqkv = dqkv; a.delta = delta;
+#ifdef LDM_ATTN_TIMING
+  { const char *tb = getenv("LDM_ATTN_TIMING_BUF"); a.timing = tb ? (unsigned long long *)strtoull(tb, nullptr, 0) : nullptr; }
+#endif
   int rc = check(a);
   if (rc) return rc;
   if (!aligned_to(qkv, 16) || !aligned_to(dout, 16) || !aligned_to(o, 8) || !aligned_to(dqkv, 8)) return LDM_E_ALIGN;
