@@ -1125,10 +1125,12 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
   if (key < S && a.key_valid) key_byte = a.key_valid[(int64_t)b * S + key];
   asm volatile("" : "+v"(key_byte));
   const bool key_ok = key < S && key_byte != 0;
-  // a padded key starts its score accumulator at -infinity: its probabilities come out of the exponential as
-  // zeros, with no select per element
-  // (the dropout variant sits at the register limit and keeps the select: key_bias is a constant there)
-  const float key_bias = (DROP || key_ok) ? 0.f : -INFINITY;
+  // a padded key starts its score accumulator at -infinity (a select on the 16 initial values, where the
+  // negation of the log-sum-exp was anyway): its probabilities come out of the exponential as zeros, with
+  // no select per element afterwards.  Not by adding a bias of -infinity: a fully padded sequence has a
+  // log-sum-exp of -infinity, and the sum would be a NaN.
+  // (the dropout variant sits at the register limit and keeps the select per element)
+  const bool key_init_ok = DROP || key_ok;
   f16_t dk[T::ND], dv[T::ND];
 #pragma unroll
   for (int i = 0; i < T::ND; ++i)
@@ -1175,8 +1177,8 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       for (int r4 = 0; r4 < 4; ++r4) {
         const float4 l4 = make_float4(lq[r4][0], lq[r4][1], lq[r4][2], lq[r4][3]);
         const float4 d4 = make_float4(dq4[r4][0], dq4[r4][1], dq4[r4][2], dq4[r4][3]);
-        s0[4 * r4 + 0] = key_bias - l4.x; s0[4 * r4 + 1] = key_bias - l4.y;
-        s0[4 * r4 + 2] = key_bias - l4.z; s0[4 * r4 + 3] = key_bias - l4.w;
+        s0[4 * r4 + 0] = key_init_ok ? -l4.x : -INFINITY; s0[4 * r4 + 1] = key_init_ok ? -l4.y : -INFINITY;
+        s0[4 * r4 + 2] = key_init_ok ? -l4.z : -INFINITY; s0[4 * r4 + 3] = key_init_ok ? -l4.w : -INFINITY;
         if constexpr (DROP) {   // the mask applies to dP alone: -delta is added after the products
           nd[4 * r4 + 0] = -d4.x; nd[4 * r4 + 1] = -d4.y; nd[4 * r4 + 2] = -d4.z; nd[4 * r4 + 3] = -d4.w;
           dpacc[4 * r4 + 0] = 0.f; dpacc[4 * r4 + 1] = 0.f; dpacc[4 * r4 + 2] = 0.f; dpacc[4 * r4 + 3] = 0.f;
