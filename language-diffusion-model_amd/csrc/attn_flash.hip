@@ -28,6 +28,9 @@ typedef float f16_t __attribute__((ext_vector_type(16)));
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+#define LDS_PTR2(p) ((__attribute__((address_space(3))) void *)(p))
+#define GLB_PTR2(p) ((const __attribute__((address_space(1))) void *)(p))
+
 template <int DP>
 struct AT {
   static constexpr int NK = DP / 16;          // 16-deep k steps over the head dim
@@ -538,8 +541,6 @@ struct Lay {
   }
 };
 
-#define LDS_PTR2(p) ((__attribute__((address_space(3))) void *)(p))
-#define GLB_PTR2(p) ((const __attribute__((address_space(1))) void *)(p))
 
 // The PW LDS-DMA pieces (1 KiB each) of a 64-row image that one of the 4 waves issues.
 template <int DP>
@@ -559,9 +560,10 @@ struct TileDma {
       off[i] = (unsigned)(row * (int)(2 * ld) + L::pos(slot, row) * 16);   // pos() is its own inverse
     }
   }
-  // piece i of tile t -> image `img`; rows >= S re-read row S-1 (finite values; masked later)
+  // piece i of tile t -> image `img`; rows >= S re-read row S-1 (finite values; masked later).
+  // Tile t must hold at least one row (64 t < S): the clamp steps back inside the tile only.
   __device__ __forceinline__ void issue_one(int i, int t, int S, int64_t ld, char *img, int wave) const {
-    const int lim = S - 64 * t;            // wave-uniform
+    const int lim = S - 64 * t;            // wave-uniform, >= 1
     int64_t toff = (int64_t)t * step;      // a scalar product: the tile's base stays in scalar registers
     asm volatile("" : "+s"(toff));
     const char *tb = base + toff;
@@ -697,9 +699,28 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
   kd.issue(0, S, a.ld, smem, wave);
   vd.issue(0, S, a.ld, smem + Lay<DP>::TILE, wave);
 
+  // The workgroup's own Q rows reach their lanes through the ring's second buffer (whole rows by LDS-DMA into
+  // two 64-row images beside the first K/V tile, fragments by ds_read_b128; loaded 16 bytes per lane straight
+  // into the operand layout every instruction touched 32 rows).  Rows past the end re-read the last row.
   bf8_t qf[T::NK];
+  // validity byte of this lane's key in the tile about to be processed: requested a whole tile ahead (asked
+  // for at the top of its own tile it was a trip to L2 in front of every tile's barrier: +10 % with a mask)
+  unsigned key_byte = 1u;
+  {
+    const int row_blk = blk.blk * 128, s_rem = S - row_blk;
+    char *buf1 = smem + 2 * Lay<DP>::TILE;
+    TileDma<DP> qd;
+    qd.init(qb + (int64_t)row_blk * a.ld, a.ld, wave, lane);
+    qd.issue(0, s_rem, a.ld, buf1, wave);
+    qd.issue(s_rem > 64 ? 1 : 0, s_rem, a.ld, buf1 + Lay<DP>::TILE, wave);   // (short block: the first image again)
+    if (a.key_valid && lane < S) key_byte = a.key_valid[(int64_t)b * S + lane];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(key_byte) : : "memory");
+    __syncthreads();
+    const char *my1 = buf1 + (wave >> 1) * Lay<DP>::TILE;
 #pragma unroll
-  for (int kk = 0; kk < T::NK; ++kk) qf[kk] = global_frag(qb, a.ld, q < S ? q : S - 1, true, kk, half, hd);
+    for (int kk = 0; kk < T::NK; ++kk) qf[kk] = row_frag2<DP>(my1, (wave & 1) * 32 + c, kk, half);
+    // (the barrier at the top of the first tile comes before anything is written to the second buffer)
+  }
 
   f16_t oacc[T::ND];
 #pragma unroll
@@ -720,10 +741,8 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     ASTAMP(s0);
 #endif
     const int k0 = t * 64;
-    const char *Kt = smem + (t & 1) * 2 * Lay<DP>::TILE;
-    const char *Vt = Kt + Lay<DP>::TILE;
-    bool kok = (k0 + lane) < S;
-    if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
+    const char *Kt = smem + (t & 1) * 2 * Lay<DP>::TILE;   // (the V image is one image further on: vta)
+    const bool kok = (k0 + lane) < S && key_byte != 0;
     const unsigned long long valid = __ballot(kok);
     // tile t has landed (this wave's pieces); after the barrier it is visible to all and every
     // wave is done with tile t-1, whose buffer the next tile's LDS-DMA then refills
@@ -739,6 +758,7 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
     // issue that stalls on a full memory queue then overlaps matrix work already in flight
     const bool more = t + 1 < nt;
     char *nb = smem + ((t + 1) & 1) * 2 * Lay<DP>::TILE;
+    if (a.key_valid && k0 + 64 + lane < S) key_byte = a.key_valid[(int64_t)b * S + k0 + 64 + lane];
 
     ASTAMP(s1);
     f16_t sacc[2];
@@ -878,7 +898,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
   const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
   using T = AT<DP>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image), 2 images for the prologue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
@@ -906,27 +926,58 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
   kd.issue(0, S, a.ld, smem, wave);
   vd.issue(0, S, a.ld, smem + Lay<DP>::TILE, wave);
 
+  // The workgroup's own rows of Q, dO and O reach their lanes through LDS: 1-KiB LDS-DMA pieces of whole rows
+  // into 64-row images, fragments by ds_read_b128.  (As 16-byte loads straight into the operand layout every
+  // instruction touched 32 rows 4.6 KB apart: ~700 cycles per instruction, 13k cycles before the first tile,
+  // a quarter of the workgroup's lifetime at S = 512.)  Q goes to the ring's second buffer and dO to the two
+  // images behind the ring, together with the first K/V tile; O follows into the second buffer once Q has
+  // been read.  The fp8 rounding residual of O and the row's log-sum-exp are plain loads in the first trip.
   bf8_t qf[T::NK], dof[T::NK];
-  const bf16_t *ob = a.o_in + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
-  // every prologue load is requested before the first of them is used: one trip to memory for Q, dO, O, the
-  // rounding residual of O and the row's log-sum-exp (requested one group after the other, each group behind
-  // the use of the one before, the prologue was three trips: a quarter of the workgroup's lifetime at S = 512)
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
   uint4 olo[T::ND];
   delta_residual_load<DP>(a, blk, wave, lane, olo);
   const float lse_row = a.lse_in[stat];
-  bf8_t ofr[T::NK];
-#pragma unroll
-  for (int kk = 0; kk < T::NK; ++kk) {
-    qf[kk] = global_frag(qb, a.ld, qc, true, kk, half, hd);
-    dof[kk] = global_frag(dob, a.ld_o, qc, true, kk, half, hd);
-    ofr[kk] = global_frag(ob, a.ld_o, qc, true, kk, half, hd);
-  }
+  // validity byte of this lane's key in the tile about to be processed, requested a whole tile ahead
+  unsigned key_byte = 1u;
+  if (a.key_valid && lane < S) key_byte = a.key_valid[(int64_t)b * S + lane];
   float dsum = 0.f;
+  {
+    const int row_blk = blk.blk * 128, s_rem = S - row_blk;
+    char *buf1 = smem + 2 * Lay<DP>::TILE, *ext = smem + 4 * Lay<DP>::TILE;
+    TileDma<DP> qd, gd;
+    qd.init(qb + (int64_t)row_blk * a.ld, a.ld, wave, lane);
+    gd.init(dob + (int64_t)row_blk * a.ld_o, a.ld_o, wave, lane);
+    // (a block of at most 64 rows has no second image: those rows are never used, and the image takes the
+    // first one's rows again -- the descriptor's 32-bit offsets cannot step back across a whole image)
+    const int t1 = s_rem > 64 ? 1 : 0;
+    qd.issue(0, s_rem, a.ld, buf1, wave);
+    gd.issue(0, s_rem, a.ld_o, ext, wave);
+    qd.issue(t1, s_rem, a.ld, buf1 + Lay<DP>::TILE, wave);
+    gd.issue(t1, s_rem, a.ld_o, ext + Lay<DP>::TILE, wave);
+    const char *my1 = buf1 + (wave >> 1) * Lay<DP>::TILE, *mye = ext + (wave >> 1) * Lay<DP>::TILE;
+    const int myrow = (wave & 1) * 32 + c;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll
-  for (int kk = 0; kk < T::NK; ++kk)
+    for (int kk = 0; kk < T::NK; ++kk) {
+      qf[kk] = row_frag2<DP>(my1, myrow, kk, half);
+      dof[kk] = row_frag2<DP>(mye, myrow, kk, half);
+    }
+    __syncthreads();   // every wave holds its Q fragments: O may take their place
+    TileDma<DP> od;
+    od.init(a.o_in + ((int64_t)b * S + row_blk) * a.ld_o + (int64_t)head * hd, a.ld_o, wave, lane);
+    od.issue(0, s_rem, a.ld_o, buf1, wave);
+    od.issue(t1, s_rem, a.ld_o, buf1 + Lay<DP>::TILE, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dsum = fmaf((float)ofr[kk][j], (float)dof[kk][j], dsum);
+    for (int kk = 0; kk < T::NK; ++kk) {
+      const bf8_t of = row_frag2<DP>(my1, myrow, kk, half);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsum = fmaf((float)of[j], (float)dof[kk][j], dsum);
+    }
+    // (the barrier at the top of the first tile comes before anything is written to the second buffer)
+  }
   dsum += delta_residual<DP>(olo, dof);
   const float dlt = dsum + __shfl_xor(dsum, 32, 64);
   const unsigned drop_row = DROP ? ldm_drop_row(ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)), a.seed_hi, (unsigned)q) : 0u;
@@ -941,22 +992,34 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 
 #ifdef LDM_ATTN_TIMING
   unsigned long long t_loop0; ASTAMP(t_loop0);
+  unsigned long long tw_vm = 0, tw_bar = 0;
 #endif
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
     const int k0 = t * 64;
     const char *Kt = smem + (t & 1) * 2 * Lay<DP>::TILE;
     const char *Vt = Kt + Lay<DP>::TILE;
-    bool kok = (k0 + lane) < S;
-    if (kok && a.key_valid) kok = a.key_valid[(int64_t)b * S + k0 + lane] != 0;
+    const bool kok = (k0 + lane) < S && key_byte != 0;
     const unsigned long long bal = __ballot(kok);
     const bool all_valid = bal == ~0ull;          // wave-uniform: the common tile has no padded key
     const unsigned long long vs = bal >> (4 * half);
+#ifdef LDM_ATTN_TIMING
+    unsigned long long w0, w1, w2;
+    ASTAMP(w0);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LDM_ATTN_TIMING
+    ASTAMP(w1);
+#endif
     __syncthreads();
+#ifdef LDM_ATTN_TIMING
+    ASTAMP(w2);
+    tw_vm += w1 - w0; tw_bar += w2 - w1;
+#endif
     // the next tile's LDS-DMA goes out one instruction at a time between the first MFMAs
     const bool more = t + 1 < nt;
     char *nb = smem + ((t + 1) & 1) * 2 * Lay<DP>::TILE;
+    if (a.key_valid && k0 + 64 + lane < S) key_byte = a.key_valid[(int64_t)b * S + k0 + 64 + lane];
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk) {
       f16_t sacc, dpacc;
@@ -1055,6 +1118,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
 #ifdef LDM_ATTN_TIMING
   if (a.timing && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 8) {
     unsigned long long te; ASTAMP(te);
+    a.timing[29] = tw_vm; a.timing[30] = tw_bar;
     a.timing[24] = t_loop0 - t_entry; a.timing[25] = t_loop1 - t_loop0; a.timing[26] = te - t_loop1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long td; ASTAMP(td);
@@ -1075,7 +1139,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 #endif
   using T = AT<DP>;
   constexpr int BUF = 2 * Lay<DP>::TILE + 512;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q image, dO image, lse[64], delta[64])
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q image, dO image, lse[64], delta[64]), 2 images for the prologue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
@@ -1087,7 +1151,6 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
   const bf16_t *kb = qb + D, *vb = qb + 2 * D;
   const bf16_t *dob = a.dout + (int64_t)b * S * a.ld_o + (int64_t)head * hd;
   const int key = blk.blk * 128 + wave * 32 + c;
-  const int keyc = key < S ? key : S - 1;
   const unsigned drop_bh = DROP ? ldm_drop_bh(a.seed_lo, (unsigned)(b * a.H + head)) : 0u;
   const int64_t stat0 = ((int64_t)b * a.H + head) * S;
 
@@ -1113,17 +1176,39 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
   gd.issue(0, S, a.ld_o, smem + Lay<DP>::TILE, wave);
   issue_stats(0, smem);
 
+  // The workgroup's own K and V rows reach their lanes through LDS (whole rows by LDS-DMA into 64-row images,
+  // fragments by ds_read_b128; loaded 16 bytes per lane straight into the operand layout every instruction
+  // touched 32 rows): K into the second buffer, V into the two images behind the buffers, beside the first
+  // Q/dO tile.  Rows past the end re-read the last row; their keys are masked below.
   bf8_t kf[T::NK], vf[T::NK];
-#pragma unroll
-  for (int kk = 0; kk < T::NK; ++kk) {
-    kf[kk] = global_frag(kb, a.ld, keyc, key < S, kk, half, hd);
-    vf[kk] = global_frag(vb, a.ld, keyc, key < S, kk, half, hd);
+  {
+    const int row_blk = blk.blk * 128, s_rem = S - row_blk;
+    char *buf1 = smem + BUF, *ext = smem + 2 * BUF;
+    TileDma<DP> kd2, vd2;
+    kd2.init(kb + (int64_t)row_blk * a.ld, a.ld, wave, lane);
+    vd2.init(vb + (int64_t)row_blk * a.ld, a.ld, wave, lane);
+    const int t1 = s_rem > 64 ? 1 : 0;   // (a block of at most 64 rows: the second image repeats the first)
+    kd2.issue(0, s_rem, a.ld, buf1, wave);
+    vd2.issue(0, s_rem, a.ld, ext, wave);
+    kd2.issue(t1, s_rem, a.ld, buf1 + Lay<DP>::TILE, wave);
+    vd2.issue(t1, s_rem, a.ld, ext + Lay<DP>::TILE, wave);
   }
   // the key's validity byte travels with the loads above (asked for first and compared at once, it was a
   // trip to memory of its own before anything else had been requested)
   unsigned key_byte = 1u;
   if (key < S && a.key_valid) key_byte = a.key_valid[(int64_t)b * S + key];
-  asm volatile("" : "+v"(key_byte));
+  {
+    const char *myk = smem + BUF + (wave >> 1) * Lay<DP>::TILE, *myv = smem + 2 * BUF + (wave >> 1) * Lay<DP>::TILE;
+    const int myrow = (wave & 1) * 32 + c;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(key_byte) : : "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < T::NK; ++kk) {
+      kf[kk] = row_frag2<DP>(myk, myrow, kk, half);
+      vf[kk] = row_frag2<DP>(myv, myrow, kk, half);
+    }
+    // (the barrier at the top of the first tile comes before anything is written to the second buffer)
+  }
   const bool key_ok = key < S && key_byte != 0;
   // a padded key starts its score accumulator at -infinity (a select on the 16 initial values, where the
   // negation of the log-sum-exp was anyway): its probabilities come out of the exponential as zeros, with
@@ -1139,6 +1224,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 
 #ifdef LDM_ATTN_TIMING
   unsigned long long t_loop0; ASTAMP(t_loop0);
+  unsigned long long tw_vm = 0, tw_bar = 0;
 #endif
   const int nt = (S + 63) / 64;
   for (int t = 0; t < nt; ++t) {
@@ -1147,8 +1233,19 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     const float *lse_s = reinterpret_cast<const float *>(Qt + 2 * Lay<DP>::TILE);
     // (delta follows lse: 64 floats on)
     const int lim = S - t * 64;   // query rows of this tile that exist
+#ifdef LDM_ATTN_TIMING
+    unsigned long long w0, w1, w2;
+    ASTAMP(w0);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LDM_ATTN_TIMING
+    ASTAMP(w1);
+#endif
     __syncthreads();
+#ifdef LDM_ATTN_TIMING
+    ASTAMP(w2);
+    tw_vm += w1 - w0; tw_bar += w2 - w1;
+#endif
     // next tile: the statistics now, the images one LDS-DMA instruction at a time between the first MFMAs
     const bool more = t + 1 < nt;
     char *nb = smem + ((t + 1) & 1) * BUF;
@@ -1276,7 +1373,11 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
   __syncthreads();
   {
     const int k0w = blk.blk * 128 + wave * 32;
-    if (a.rope_cos) unrope_acc<DP>(dk, 1.0f, half, a.rope_cos + (int64_t)keyc * (DP / 2), a.rope_sin + (int64_t)keyc * (DP / 2));
+    if (a.rope_cos) {
+      // (the tables' rows straight from memory: staging them through LDS as the prologues do measured 0.7 % slower)
+      const int keyc = key < S ? key : S - 1;
+      unrope_acc<DP>(dk, 1.0f, half, a.rope_cos + (int64_t)keyc * (DP / 2), a.rope_sin + (int64_t)keyc * (DP / 2));
+    }
     if (aligned_to_dev(a.dqkv, 16)) {
       char *wl = smem + wave * 32 * T::RSTR;
       bf16_t *row0 = a.dqkv + ((int64_t)b * S + k0w) * a.ld + (int64_t)head * hd;
@@ -1291,6 +1392,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
 #ifdef LDM_ATTN_TIMING
   if (a.timing && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 8) {
     unsigned long long te; ASTAMP(te);
+    a.timing[37] = tw_vm; a.timing[38] = tw_bar;
     a.timing[32] = t_loop0 - t_entry; a.timing[33] = t_loop1 - t_loop0; a.timing[34] = te - t_loop1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long td; ASTAMP(td);
@@ -1604,7 +1706,7 @@ bool attn_dma_enabled() {
 
 template <int DP, bool DROP>
 int flash2_bwd_launch_t(const FArgs &a, hipStream_t s) {
-  constexpr int lds_dq = 4 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512);
+  constexpr int lds_dq = 6 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512) + 2 * Lay<DP>::TILE;
   static std::atomic<uint64_t> attr_done{0};
   uint64_t dev_bit;
   if (ldm_attr_pending(attr_done, &dev_bit)) {

@@ -14,11 +14,21 @@ lib = N.lib()
 saved = torch.empty(lib.ldm_attn_saved_bytes(1, B, H, S, hd), dtype=torch.uint8, device=dev)
 dqkv = torch.empty_like(qkv)
 ws = torch.empty(lib.ldm_attn_bwd_ws_bytes(1, B, H, S, hd), dtype=torch.uint8, device=dev)
+UNROPE = bool(os.environ.get("UNROPE"))     # the step's form: rotary backward inside the attention backward's stores
+MASK = bool(os.environ.get("MASK"))         # the step's form: an all-ones key-validity mask instead of none
+if UNROPE:
+    ang = torch.arange(S, device=dev, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, device=dev, dtype=torch.float32) / hd))[None, :]
+    cos_t, sin_t = ang.cos().contiguous(), ang.sin().contiguous()
+kv = torch.ones(B, S, dtype=torch.uint8, device=dev) if MASK else None
 def fwd():
-    N.check(lib.ldm_attn_fwd(1, qkv.data_ptr(), 3 * D, None, B, H, S, hd, o.data_ptr(), D, saved.data_ptr(), N.stream()), "fwd")
+    N.check(lib.ldm_attn_fwd(1, qkv.data_ptr(), 3 * D, N.ptr(kv), B, H, S, hd, o.data_ptr(), D, saved.data_ptr(), N.stream()), "fwd")
 def bwd():
-    N.check(lib.ldm_attn_bwd(1, qkv.data_ptr(), 3 * D, None, B, H, S, hd, o.data_ptr(), go.data_ptr(), D, saved.data_ptr(),
-                             dqkv.data_ptr(), ws.data_ptr(), N.stream()), "bwd")
+    if UNROPE:
+        N.check(lib.ldm_attn_bwd_unrope(1, qkv.data_ptr(), 3 * D, N.ptr(kv), B, H, S, hd, o.data_ptr(), go.data_ptr(), D, saved.data_ptr(),
+                                        dqkv.data_ptr(), ws.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), 1.0 / hd ** 0.5, N.stream()), "bwd")
+    else:
+        N.check(lib.ldm_attn_bwd(1, qkv.data_ptr(), 3 * D, N.ptr(kv), B, H, S, hd, o.data_ptr(), go.data_ptr(), D, saved.data_ptr(),
+                                 dqkv.data_ptr(), ws.data_ptr(), N.stream()), "bwd")
 def timeit(fn, reps=20):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

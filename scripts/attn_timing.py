@@ -44,4 +44,5 @@ rounds = B * H * ((S + 127) // 128) / 512
 print(f"bwd {e0.elapsed_time(e1) * 1e3:.1f} us (instrumented), {e0.elapsed_time(e1) * 1e3 / rounds:.2f} us per round of workgroups (both kernels)")
 for nm, b0 in (("dQ", 24), ("dK/dV", 32)):
     print(f"  {nm}: a workgroup from the middle of the grid, cycles: entry -> first tile {int(t[b0])}  tile loop {int(t[b0 + 1])}"
-          f"  loop end -> stores issued {int(t[b0 + 2])}  stores drained {int(t[b0 + 3])}; lifetime {t[b0 + 4].item() / 100:.2f} us")
+          f"  loop end -> stores issued {int(t[b0 + 2])}  stores drained {int(t[b0 + 3])}; lifetime {t[b0 + 4].item() / 100:.2f} us;"
+          f" of the tile loop: waiting for the LDS-DMA {int(t[b0 + 5])}, at the barrier {int(t[b0 + 6])}")
