@@ -767,12 +767,13 @@ static int rmsnorm_fwd_launch(const void *x, const float *w, int64_t rows, int64
   const unsigned grid = stream_grid(rows, 4);
   const T *xx = (const T *)x;
   T *yy = (T *)y;
-  if (d % 8 == 0 && aligned_to(w, 16) && rms_nv8(d) <= 4) {
+  if (d % 8 == 0 && aligned_to(w, 16) && rms_nv8(d) <= 8) {
 #define RMS_F8(NV) hipLaunchKernelGGL((rmsnorm_fwd8_k<T, NV>), dim3(grid), dim3(256), 0, s, xx, w, rows, (int)d, eps, yy, rstd)
     switch (rms_nv8(d)) {
       case 1: RMS_F8(1); break;
       case 2: RMS_F8(2); break;
-      default: RMS_F8(4); break;
+      case 4: RMS_F8(4); break;
+      default: RMS_F8(8); break;   // rows of up to 4096 elements (the LLaDA-8B width)
     }
 #undef RMS_F8
     LDM_CHECK_LAUNCH();
@@ -819,7 +820,7 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
   if (blocks > max_blocks) blocks = max_blocks;
   const unsigned grid = (unsigned)blocks;
   const size_t lds = (size_t)4 * d * sizeof(float);
-  if (d % 8 == 0 && rms_nv8(d) <= 4) {
+  if (d % 8 == 0 && rms_nv8(d) <= 8) {
 #define RMS_B8(NV)                                                                                                \
   do {                                                                                                            \
     if (dres)                                                                                                     \
@@ -832,7 +833,8 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
     switch (rms_nv8(d)) {
       case 1: RMS_B8(1); break;
       case 2: RMS_B8(2); break;
-      default: RMS_B8(4); break;
+      case 4: RMS_B8(4); break;
+      default: RMS_B8(8); break;
     }
 #undef RMS_B8
     LDM_CHECK_LAUNCH();
