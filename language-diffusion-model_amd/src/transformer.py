@@ -332,12 +332,21 @@ class DiffusionTransformer(nn.Module):
             x = layer(x, src_key_padding_mask=key_padding_mask)
         return self.norm(x)
 
+    # Accelerate wraps the reference's forward so that the bf16 logits of its autocast Linear come back as
+    # fp32 (``convert_outputs_to_fp32``): the same values, up-cast after the fact.  ``fp32_logits = True``
+    # does exactly that here (one more pass over [B,S,V]; the trainer's fused head loss never forms them).
+    fp32_logits: bool = False
+
     def forward(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:
-        """input_ids [B,S] (+ attention_mask [B,S]) -> logits [B,S,V] in compute_dtype.
+        """input_ids [B,S] (+ attention_mask [B,S]) -> logits [B,S,V] in compute_dtype (fp32 with
+        ``fp32_logits``).
 
         The logits rows are stored with a stride padded to 64 columns; the returned
         tensor is the [B,S,V] view of that buffer."""
-        return ops.packed_linear(self.hidden_states(input_ids, attention_mask), self._head_pack())
+        logits = ops.packed_linear(self.hidden_states(input_ids, attention_mask), self._head_pack())
+        if self.fp32_logits and logits.dtype != torch.float32:
+            return logits.float()
+        return logits
 
     def masked_token_loss(self, masked_input_ids: Tensor, targets: Tensor, mask_token_id: int,
                           attention_mask: Tensor | None = None, *, seq_weight: Tensor | None = None,

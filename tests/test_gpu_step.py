@@ -473,3 +473,31 @@ def test_long_sequence_wide_model_properties(dev):
             continue
         assert rel_err(gf[n], gd[n]) < 5e-3, n
     assert float(gf["embedding.weight"][0].abs().max()) == 0.0      # pad id: masked out of loss and never a key
+
+
+@pytest.mark.gpu
+def test_fp32_logits_switch_is_an_upcast_of_the_bf16_logits(dev):
+    """DiffusionTransformer.fp32_logits: what Accelerate's output conversion gives the reference under bf16
+    (fp32 logits holding the bf16 values); loss and gradients through them equal the bf16-logits path's."""
+    from src.loss import variational_lower_bound_loss
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    torch.manual_seed(3)
+    tr = DiffusionTransformer(DiffusionTransformerConfig(vocab_size=1000, d_model=64, nhead=2, num_layers=2,
+                                                         dim_feedforward=128, dropout=0.0)).to(dev)
+    tr.set_compute_dtype(torch.bfloat16).train()
+    ids = torch.randint(5, 1000, (2, 128), device=dev)
+    masked = ids.clone()
+    masked[:, ::3] = 103
+    l16 = tr(masked)
+    loss16 = variational_lower_bound_loss(l16, ids, masked, 103)
+    loss16.backward()
+    g16 = {n: p.grad.clone() for n, p in tr.named_parameters()}
+    tr.zero_grad()
+    tr.fp32_logits = True
+    l32 = tr(masked)
+    assert l32.dtype == torch.float32 and torch.equal(l32, l16.float())
+    loss32 = variational_lower_bound_loss(l32, ids, masked, 103)
+    loss32.backward()
+    assert abs(loss32.item() - loss16.item()) < 1e-3 * abs(loss16.item())
+    for n, p in tr.named_parameters():
+        assert rel_err(p.grad, g16[n]) < 2e-2, n
