@@ -892,13 +892,14 @@ __global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
 
 // --------------------------------------------------------------------------- dQ, LDS-DMA tiles
 template <int DP, bool DROP>
-__global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs a) {
+// (two workgroups per CU; the dropout variant at head dim 128 would spill 11 registers and keeps one)
+__global__ __launch_bounds__(256, (DP == 128 && DROP) ? 1 : 2) void flash2_bwd_dq_k(FArgs a) {
 #ifdef LDM_ATTN_TIMING
   unsigned long long t_entry; ASTAMP(t_entry);
   const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
   using T = AT<DP>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image), 2 images for the prologue
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K image, V image)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
@@ -923,15 +924,14 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
   TileDma<DP> kd, vd;
   kd.init(kb, a.ld, wave, lane);
   vd.init(vb, a.ld, wave, lane);
-  kd.issue(0, S, a.ld, smem, wave);
-  vd.issue(0, S, a.ld, smem + Lay<DP>::TILE, wave);
 
   // The workgroup's own rows of Q, dO and O reach their lanes through LDS: 1-KiB LDS-DMA pieces of whole rows
   // into 64-row images, fragments by ds_read_b128.  (As 16-byte loads straight into the operand layout every
   // instruction touched 32 rows 4.6 KB apart: ~700 cycles per instruction, 13k cycles before the first tile,
-  // a quarter of the workgroup's lifetime at S = 512.)  Q goes to the ring's second buffer and dO to the two
-  // images behind the ring, together with the first K/V tile; O follows into the second buffer once Q has
-  // been read.  The fp8 rounding residual of O and the row's log-sum-exp are plain loads in the first trip.
+  // a quarter of the workgroup's lifetime at S = 512.)  Two trips, inside the ring's four images: Q into the
+  // second buffer and dO into the first; then, once their fragments are in registers, O into the second
+  // buffer beside the first K/V tile into the first.  The fp8 rounding residual of O and the row's
+  // log-sum-exp are plain loads in the first trip.
   bf8_t qf[T::NK], dof[T::NK];
   const int64_t stat = ((int64_t)b * a.H + head) * S + qc;
   uint4 olo[T::ND];
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
   float dsum = 0.f;
   {
     const int row_blk = blk.blk * 128, s_rem = S - row_blk;
-    char *buf1 = smem + 2 * Lay<DP>::TILE, *ext = smem + 4 * Lay<DP>::TILE;
+    char *buf1 = smem + 2 * Lay<DP>::TILE, *ext = smem;   // (dO borrows the first buffer before K/V arrive)
     TileDma<DP> qd, gd;
     qd.init(qb + (int64_t)row_blk * a.ld, a.ld, wave, lane);
     gd.init(dob + (int64_t)row_blk * a.ld_o, a.ld_o, wave, lane);
@@ -963,7 +963,9 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dq_k(FArgs 
       qf[kk] = row_frag2<DP>(my1, myrow, kk, half);
       dof[kk] = row_frag2<DP>(mye, myrow, kk, half);
     }
-    __syncthreads();   // every wave holds its Q fragments: O may take their place
+    __syncthreads();   // every wave holds its Q and dO fragments: K/V and O may take their place
+    kd.issue(0, S, a.ld, smem, wave);
+    vd.issue(0, S, a.ld, smem + Lay<DP>::TILE, wave);
     TileDma<DP> od;
     od.init(a.o_in + ((int64_t)b * S + row_blk) * a.ld_o + (int64_t)head * hd, a.ld_o, wave, lane);
     od.issue(0, s_rem, a.ld_o, buf1, wave);
@@ -1706,7 +1708,7 @@ bool attn_dma_enabled() {
 
 template <int DP, bool DROP>
 int flash2_bwd_launch_t(const FArgs &a, hipStream_t s) {
-  constexpr int lds_dq = 6 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512) + 2 * Lay<DP>::TILE;
+  constexpr int lds_dq = 4 * Lay<DP>::TILE, lds_dkv = 2 * (2 * Lay<DP>::TILE + 512) + 2 * Lay<DP>::TILE;
   static std::atomic<uint64_t> attr_done{0};
   uint64_t dev_bit;
   if (ldm_attr_pending(attr_done, &dev_bit)) {
