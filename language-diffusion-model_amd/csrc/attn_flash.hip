@@ -667,7 +667,8 @@ __device__ __forceinline__ unsigned lds_off(const void *p) {
 }
 
 template <int DP, bool DROP>
-__global__ __launch_bounds__(256, 2) void flash2_fwd_k(FArgs a) {
+// (head dim 96: three workgroups per CU -- 155 registers, 164 with dropout once the compiler is held to 168)
+__global__ __launch_bounds__(256, DP == 96 ? 3 : 2) void flash2_fwd_k(FArgs a) {
 #ifdef LDM_ATTN_TIMING
   unsigned long long t_entry; ASTAMP(t_entry);
   const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
