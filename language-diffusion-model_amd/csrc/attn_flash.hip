@@ -1253,6 +1253,7 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
     const bool more = t + 1 < nt;
     char *nb = smem + ((t + 1) & 1) * BUF;
     if (more) issue_stats(t + 1, nb);
+    [[maybe_unused]] const unsigned row_keys = DROP ? ldm_drop_row(drop_bh, a.seed_hi, (unsigned)(t * 64 + lane)) : 0u;
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
       // the score accumulator starts at -lse and the dP accumulator at -delta: the products then leave
@@ -1332,8 +1333,11 @@ __global__ __launch_bounds__(256, DP == 128 ? 1 : 2) void flash2_bwd_dkv_k(FArgs
       for (int r = 0; r < 16; ++r) {
         const float pr = (!DROP || key_ok) ? fast_exp2(s0[r] * LOG2E) : 0.f;
         if constexpr (DROP) {
-          const unsigned qi = (unsigned)(t * 64 + qbk * 32 + acc_row(r) + 4 * half);
-          const bool keep = ldm_drop_keep(ldm_drop_row(drop_bh, a.seed_hi, qi), (unsigned)key, a.drop_thresh);
+          // row key of query row t*64 + qbk*32 + acc_row(r) + 4*half: lane L of `row_keys` holds that of row
+          // t*64 + L (one hash round per lane and tile instead of one per element here)
+          const unsigned rk_lo = __builtin_amdgcn_readlane(row_keys, qbk * 32 + acc_row(r));
+          const unsigned rk_hi = __builtin_amdgcn_readlane(row_keys, qbk * 32 + acc_row(r) + 4);
+          const bool keep = ldm_drop_keep(half ? rk_hi : rk_lo, (unsigned)key, a.drop_thresh);
           p[r] = keep ? pr * a.drop_inv : 0.f;
           ds[r] = pr * ((keep ? dpacc[r] * a.drop_inv : 0.f) + nd[r]);
         } else {
