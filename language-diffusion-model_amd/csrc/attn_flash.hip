@@ -705,7 +705,8 @@ __global__ __launch_bounds__(256, DP == 96 ? 3 : 2) void flash2_fwd_k(FArgs a) {
   // into the operand layout every instruction touched 32 rows).  Rows past the end re-read the last row.
   bf8_t qf[T::NK];
   // validity byte of this lane's key in the tile about to be processed: requested a whole tile ahead (asked
-  // for at the top of its own tile it was a trip to L2 in front of every tile's barrier: +10 % with a mask)
+  // for at the top of its own tile it was a trip to L2 in front of every tile's barrier: 2.5 % of the
+  // forward with the step's all-ones mask)
   unsigned key_byte = 1u;
   {
     const int row_blk = blk.blk * 128, s_rem = S - row_blk;
