@@ -1250,6 +1250,7 @@ int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int6
       if (sp == 1 || cost < best * 0.97) { best = cost; splits = sp; }
     }
   }
+  if (const char *e = getenv("LDM_GEMM_SPLITS")) { if (atoi(e) > 0) splits = atoi(e); }   // experiments only
   // measured: with >= 9 tiles and >= 64 half-tiles per work item the persistent 256-row kernel
   // wins (861 vs 625 TFLOP/s at 2304x768x65536; equal to the 128x128 kernel at 768x768x65536 on
   // cache-warm operands, ~15 % faster inside the training step, where the operands come from HBM
