@@ -181,24 +181,11 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// 16 (rows or cols) x 32 k fragment of a half-tile image
-template <bool KC, int ROWS>
-__device__ __forceinline__ bf8_t read_frag(const char *img, int rbase, int lane) {
-  if (KC) {
-    const int r = rbase + (lane & 15);
-    const int pc = (lane >> 4) ^ swz_kc(r);
-    return *reinterpret_cast<const bf8_t *>(img + r * 64 + pc * 16);
-  } else {
-    constexpr int RB = ROWS * 2;
-    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int kr0 = 8 * g + q;
-    const int ch = ((rbase >> 3) + (p >> 1)) ^ swz_st(kr0);       // swz_st(kr0 + 4) == swz_st(kr0)
-    const char *a0 = img + kr0 * RB + (ch << 4) + ((p & 1) << 3);
-    s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0));
-    s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a0 + 4 * RB));
-    s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf8_t, v);
-  }
+// 16 rows x 32 k fragment of a K-contiguous half-tile image (64-byte rows)
+__device__ __forceinline__ bf8_t read_frag_kc(const char *img, int rbase, int lane) {
+  const int r = rbase + (lane & 15);
+  const int pc = (lane >> 4) ^ swz_kc(r);
+  return *reinterpret_cast<const bf8_t *>(img + r * 64 + pc * 16);
 }
 
 // The strided-operand fragment as two transposing reads written as asm: behind the compiler's own
@@ -280,6 +267,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
+  // The split-K (weight-gradient) form takes its 16-row fragments of A in an order rotated by the wave's
+  // column: the fragments whose row sums this wave owns (RS of them, for the bias gradient) are then its
+  // first ones whatever the wave, and the row-sum MFMAs take them from the registers the products use.
+  // (Read a second time at addresses of their own they cost two address registers, which spilled: a scratch
+  // reload, and with it a drain of every LDS-DMA in flight, in every phase of the tiles that sum rows.)
+  auto afrag = [&](int i) { return EPI == 1 ? ((i + (MI / WN_) * wn) & (MI - 1)) : i; };
   const bool late = wave >= 4;
 
   const int64_t Mdyn = g.dyn_m ? (int64_t)*g.dyn_m : g.M;
@@ -456,27 +449,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       TSTAMP(t0);
       // ---- segment R: read p; in odd phases send pair (p+3, p+4) into the slots of p-2 and p-1 and
       // retire this wave's pieces of pair (p+1, p+2), which the next two phases read
-      const char *cur = smem + slot * HT;
       // fragments: (see SPLIT_A / SPLIT_B) the second half of one operand is requested at the start of
       // segment M and arrives under the first half's MFMAs
       constexpr int MH = SPLIT_A ? MI / 2 : MI, NH = SPLIT_B ? NI / 2 : NI;
       bf8_t fa[MH], fa2[SPLIT_A ? MH : 1], fb[NH], fb2[SPLIT_B ? NH : 1];
       [[maybe_unused]] s4_t alo[MH], ahi[MH], alo2[SPLIT_A ? MH : 1], ahi2[SPLIT_A ? MH : 1], blo[NH], bhi[NH];
+      [[maybe_unused]] const char *cur = smem + slot * HT;
       [[maybe_unused]] const unsigned cur_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + slot * HT;
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
-        if constexpr (B_KC) fb[i] = read_frag<true, BN>(cur + HT_A, wn * 64 + i * 16, lane);
+        if constexpr (B_KC) fb[i] = read_frag_kc(cur + HT_A, wn * 64 + i * 16, lane);
         else tr_issue<BN>(cur_lds + HT_A, wn * 64 + i * 16, lane, blo[i], bhi[i]);
       }
 #pragma unroll
       for (int i = 0; i < MH; ++i) {
-        if constexpr (A_KC) fa[i] = read_frag<true, BM>(cur, wm * (MI * 16) + i * 16, lane);
-        else tr_issue<BM>(cur_lds, wm * (MI * 16) + i * 16, lane, alo[i], ahi[i]);
+        if constexpr (A_KC) fa[i] = read_frag_kc(cur, wm * (MI * 16) + afrag(i) * 16, lane);
+        else tr_issue<BM>(cur_lds, wm * (MI * 16) + afrag(i) * 16, lane, alo[i], ahi[i]);
       }
-      // row sums: this wave's RS fragments of opA are read a second time, in segment M (the choice depends
-      // on the wave, and choosing among registers costs a chain of branches in every phase)
-      [[maybe_unused]] bf8_t fr[RS];
-      [[maybe_unused]] s4_t rlo[RS], rhi[RS];
       {
         const int rem = np - p;             // half-tiles left, this one included
         const bool more3 = rem > 3;
@@ -525,19 +514,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       if constexpr (SPLIT_A) {
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
-          if constexpr (A_KC) fa2[i] = read_frag<true, BM>(cur, wm * (MI * 16) + (MH + i) * 16, lane);
-          else tr_issue<BM>(cur_lds, wm * (MI * 16) + (MH + i) * 16, lane, alo2[i], ahi2[i]);
+          if constexpr (A_KC) fa2[i] = read_frag_kc(cur, wm * (MI * 16) + afrag(MH + i) * 16, lane);
+          else tr_issue<BM>(cur_lds, wm * (MI * 16) + afrag(MH + i) * 16, lane, alo2[i], ahi2[i]);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < NH; ++i) fb2[i] = read_frag<true, BN>(cur + HT_A, wn * 64 + (NH + i) * 16, lane);
-      }
-      if (EPI == 1 && do_rowsum) {
-#pragma unroll
-        for (int j = 0; j < RS; ++j) {
-          if constexpr (A_KC) fr[j] = read_frag<true, BM>(cur, wm * (MI * 16) + (wn * RS + j) * 16, lane);
-          else tr_issue<BM>(cur_lds, wm * (MI * 16) + (wn * RS + j) * 16, lane, rlo[j], rhi[j]);
-        }
+        for (int i = 0; i < NH; ++i) fb2[i] = read_frag_kc(cur + HT_A, wn * 64 + (NH + i) * 16, lane);
       }
       // (Measured: sending this part of the pair behind the first eight MFMAs, or one instruction at a time
       // between groups of four MFMAs, or starting the segment with four MFMAs, is no faster than this.)
@@ -555,8 +537,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           for (int ni = 0; ni < NI; ++ni)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         if constexpr (!A_KC) {
+          // the wait for the second half stays HERE, behind the sixteen MFMAs that cover the reads (unpinned
+          // it moves up to the first MFMA of the segment).  (The K-contiguous reads are the compiler's own:
+          // its wait for them lands in front of the first MFMA, behind the LDS-DMA requests that cover
+          // them; as asm with the wait pinned here the forward GEMMs measured 1 % slower.)
+          __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           tr_done<MH>(alo2, ahi2, fa2);
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi)
@@ -579,13 +567,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       offB += kstepB;
       asm volatile("" : "+s"(offA), "+s"(offB));   // stay scalar (else: one running VGPR pointer pair per piece)
       if (EPI == 1 && do_rowsum) {
-        if constexpr (!A_KC) {
-          if constexpr (!SPLIT_A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          tr_done<RS>(rlo, rhi, fr);
-        }
+        static_assert(RS <= MH, "the row-sum fragments are among the first half's");
         const bf8_t ones = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-        for (int j = 0; j < RS; ++j) racc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[j], racc[j], 0, 0, 0);
+        for (int j = 0; j < RS; ++j) racc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[j], racc[j], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
       TSTAMP(t4);
@@ -895,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
         *reinterpret_cast<float4 *>(cs + row * 64 + ((c4 ^ row) << 2)) =
             make_float4(a[0] * g.alpha, a[1] * g.alpha, a[2] * g.alpha, a[3] * g.alpha);
       }
-      const int64_t mw = m0 + wm * (MI * 16) + mi * 16;
+      const int64_t mw = m0 + wm * (MI * 16) + afrag(mi) * 16;
       if (EPI == 1) {
         float *C = (float *)g.C;
         const int64_t n = nw + lane;
