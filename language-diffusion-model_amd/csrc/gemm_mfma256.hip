@@ -181,6 +181,24 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// wait_vm<n> for an n that is a constant only after unrolling
+template <int LO, int HI>
+__device__ __forceinline__ void wait_vm_sw(int n) {
+  if constexpr (LO == HI) wait_vm<LO>();
+  else {
+    constexpr int MID = (LO + HI) / 2;
+    if (n <= MID) wait_vm_sw<LO, MID>(n); else wait_vm_sw<MID + 1, HI>(n);
+  }
+}
+// 16-byte global load whose wait the caller places (wait_vm + a launder of `v`): the reading epilogues
+// count their own stores and the next item's prefetch into the wait.  The compiler's own wait for such a
+// load is vmcnt(0) there -- for every store of the epilogue so far and the whole prefetch.
+typedef unsigned u4g_t __attribute__((ext_vector_type(4)));
+// (scalar base + 32-bit per-lane byte offset: one address register for all of a tile's loads)
+__device__ __forceinline__ void gload16(u4g_t &v, const void *sbase, unsigned lane_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(sbase) : "memory");
+}
+
 // 16 rows x 32 k fragment of a K-contiguous half-tile image (64-byte rows)
 __device__ __forceinline__ bf8_t read_frag_kc(const char *img, int rbase, int lane) {
   const int r = rbase + (lane & 15);
@@ -597,29 +615,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // loaded 16 bytes per lane exactly where the stores will go, in batches of RQ loads held in two
     // register banks: batch 0 is issued HERE, before the next item's LDS-DMA prefetch (so its
     // latency runs under the prefetch set-up), batch k+2 as soon as batch k has been consumed.
-    constexpr bool RES_FAST = RES == 1 && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
+    constexpr bool RES_FAST = (RES == 1 || RES == 5) && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
+    // RES 5: RES 1 for a problem whose every tile is full and aligned and has a residual (the host checks): no
+    // other epilogue is compiled into the variant, which leaves the registers for residual loads written as
+    // asm with counted waits
+    constexpr bool RES_FULL = RES == 5;
+    static_assert(!RES_FULL || RES_FAST, "RES 5 is a 256-column bf16 variant");
     // RES 2: C = [dh * silu(g) | dh * a * silu'(g)] with dh the product and [a | g] read from R (SwiGLU backward)
     constexpr bool SWI_FAST = RES == 2 && EPI == 0 && sizeof(TO) == 2 && MI == 8;
     typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
-    const bool fast_tile = EPI == 0 && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0;
-    const bool res_fast = RES_FAST && fast_tile && g.R != nullptr && (g.ldr % CPL) == 0;
+    const bool fast_tile = RES_FULL || (EPI == 0 && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0);
+    const bool res_fast = RES_FULL || (RES_FAST && fast_tile && g.R != nullptr && (g.ldr % CPL) == 0 && g.ldr < (1 << 27));   // (32-bit lane offset)
     // RQ loads (a quarter of the tile's 2 MI store positions) per batch, two batches in registers
     constexpr int RQ = MI / 2;
-    u4v_t rr[(RES_FAST || SWI_FAST) ? 2 * RQ : 1];   // SWI: per bank (a0, a1, g0, g1) of two store positions
-    const TO *rrow = nullptr;
+    // RES 5 holds the residual of the whole tile (four batches, all requested before the first is used)
+    u4v_t rr[RES_FULL ? 4 * RQ : (RES_FAST || SWI_FAST) ? 2 * RQ : 1];   // SWI: per bank (a0, a1, g0, g1) of two store positions
+    const TO *rrow = nullptr;        // wave-uniform: the wave's first row of R at its first column
+    int lane_e = lane;
+    if constexpr (RES == 1) asm volatile("" : "+v"(lane_e));   // (not kept across the main loop either)
+    [[maybe_unused]] const unsigned rlane = (unsigned)(((lane_e / LPR) * g.ldr + (lane_e % LPR) * CPL) * sizeof(TO));
     if (SWI_FAST) {
-      rrow = (const TO *)g.R + (m0 + wm * (MI * 16) + lane / LPR) * g.ldr + nw + (lane % LPR) * CPL;
+      rrow = (const TO *)g.R + (m0 + wm * (MI * 16)) * g.ldr + nw;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        rr[i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr);
-        rr[2 + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr + g.gate_off);
+        gload16(rr[i], rrow + (int64_t)i * RPP * g.ldr, rlane);
+        gload16(rr[2 + i], rrow + (int64_t)i * RPP * g.ldr + g.gate_off, rlane);
       }
     }
     if (RES_FAST && res_fast) {
-      rrow = (const TO *)g.R + (m0 + wm * (MI * 16) + lane / LPR) * g.ldr + nw + (lane % LPR) * CPL;
+      rrow = (const TO *)g.R + (m0 + wm * (MI * 16)) * g.ldr + nw;
 #pragma unroll
-      for (int i = 0; i < RQ; ++i)
-        rr[i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)i * RPP * g.ldr);
+      for (int i = 0; i < RQ; ++i) {
+        if constexpr (RES_FULL) gload16(rr[i], rrow + (int64_t)i * RPP * g.ldr, rlane);
+        else rr[i] = *reinterpret_cast<const u4v_t *>((const char *)(rrow + (int64_t)i * RPP * g.ldr) + rlane);
+      }
     }
 
     [[maybe_unused]] const int tid_cur_tn = tid.tn;
@@ -657,9 +686,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
       p_begin = tid.split * base + (tid.split < rem ? tid.split : rem);
       np = base + (tid.split < rem ? 1 : 0);
-      stage_ptrs<A_KC, BM>(g.A, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane, srcA);
-      if constexpr (RES == 4) stage_ptrs_rope(g.B, g.ldb, tid.tn, wave, lane, g.rope_D, g.rope_hd, srcB);
-      else stage_ptrs<B_KC, BN>(g.B, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane, srcB,
+      // (the operand bases as opaque scalars: left visible, base + per-lane column offset is hoisted out of
+      // the tile loop into a register pair per operand, which the full variants spill -- and the reload,
+      // with its wait for everything in flight, sits between the residual loads above and the prefetch)
+      // (and the lane number as an opaque value: nothing derived from it for this set-up stays in
+      // registers across the main loop)
+      // (RES 1 only, the variant at the register limit: the recomputation costs the plain input-gradient
+      // GEMMs 1 %)
+      const bf16_t *baseA = g.A, *baseB = g.B;
+      int lane_t = lane;
+#ifdef LDM_X_LAUNDER_ALL   // (experiment: every variant)
+      asm volatile("" : "+s"(baseA), "+s"(baseB), "+v"(lane_t));
+#else
+      if constexpr (RES == 1) asm volatile("" : "+s"(baseA), "+s"(baseB), "+v"(lane_t));
+#endif
+      stage_ptrs<A_KC, BM>(baseA, g.lda, (int64_t)tid.tm * BM, Mdyn, wave, lane_t, srcA);
+      if constexpr (RES == 4) stage_ptrs_rope(baseB, g.ldb, tid.tn, wave, lane_t, g.rope_D, g.rope_hd, srcB);
+      else stage_ptrs<B_KC, BN>(baseB, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane_t, srcB,
                                 RES == 3 ? g.gate_off : 0);
       issue_first();
     }
@@ -739,20 +782,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       if (!more) break;
       continue;
     }
-    if (EPI == 0 && (SWI_FAST || (fast_tile && (!g.R || res_fast)))) {
+    if (EPI == 0 && (SWI_FAST || RES_FULL || (fast_tile && (!g.R || res_fast)))) {
       TO *C = (TO *)g.C;
       if (SWI_FAST) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          rr[RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(2 + i) * RPP * g.ldr);
-          rr[RQ + 2 + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(2 + i) * RPP * g.ldr + g.gate_off);
+          gload16(rr[RQ + i], rrow + (int64_t)(2 + i) * RPP * g.ldr, rlane);
+          gload16(rr[RQ + 2 + i], rrow + (int64_t)(2 + i) * RPP * g.ldr + g.gate_off, rlane);
         }
       }
       if (RES_FAST && res_fast) {
-        // batch 1 goes out before batch 0 is used (the compiler places the waits: loads return in order)
+        // batch 1 goes out before batch 0 is used.  (In RES 1 these loads and their waits are the compiler's
+        // -- vmcnt(0) in front of every store position: with the other epilogues compiled in, the asm form
+        // spills 35 registers.  RES 5 has the asm form.)
 #pragma unroll
-        for (int i = 0; i < RQ; ++i) rr[RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(RQ + i) * RPP * g.ldr);
+        for (int i = 0; i < (RES_FULL ? 3 * RQ : RQ); ++i) {
+          if constexpr (RES_FULL) gload16(rr[RQ + i], rrow + (int64_t)(RQ + i) * RPP * g.ldr, rlane);
+          else rr[RQ + i] = *reinterpret_cast<const u4v_t *>((const char *)(rrow + (int64_t)(RQ + i) * RPP * g.ldr) + rlane);
+        }
       }
+      // Waits of the reading epilogues (RES 2, RES 5), counted (vmcnt counts loads, LDS-DMA and stores alike, in issue
+      // order).  Issue order of a wave: batch 0 | the next item's prefetch (NPF requests, if there is a next
+      // item) | batch 1 (RES 5: batches 1-3) | then per store position its stores, (RES 2) with a new batch
+      // in front of them at the positions that free a bank.  `young` = requests issued after the batch that
+      // is waited for.
+      constexpr int NPF = 2 * PI + 3 * SI;
+      [[maybe_unused]] const bool prefetched = more && np > 0;
+      // (the prefetch is younger than batch 0 only)
+      [[maybe_unused]] auto batch_wait = [&](int young, bool first) {
+        if (first && prefetched) wait_vm_sw<0, 63>(young + NPF); else wait_vm_sw<0, 63>(young);
+      };
       const int cl = lane % LPR;
       const int wrow = lane & 15;
       const unsigned waddr = stage_lds + wrow * 256;
@@ -799,6 +858,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
               constexpr int IPM = 16 / RPP;
               const int ri = mi * IPM + it;                 // store position; batches of two positions
               const int bank = (ri >> 1) & 1;
+              if ((ri & 1) == 0) {
+                // batch ri/2: behind it went (batch 0) the prefetch and batch 1; (batch 1) the stores of two
+                // positions and batch 2; (later ones) the stores of three positions and a batch; (the last)
+                // the stores of three positions
+                batch_wait(ri == 0 ? 4 : ri == 2 ? 8 : ri == 2 * MI - 2 ? 6 : 10, ri == 0);
+                asm volatile("" : "+v"(rr[bank * RQ]), "+v"(rr[bank * RQ + 1]), "+v"(rr[bank * RQ + 2]), "+v"(rr[bank * RQ + 3]));
+              }
               const u4v_t av = rr[bank * RQ + (ri & 1)], gv = rr[bank * RQ + 2 + (ri & 1)];
               float dg8[8];
 #pragma unroll
@@ -814,8 +880,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
               if ((ri & 1) && ri + 3 < 2 * MI) {             // this bank is free: the batch after next
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                  rr[bank * RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(ri + 3 + i) * RPP * g.ldr);
-                  rr[bank * RQ + 2 + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(ri + 3 + i) * RPP * g.ldr + g.gate_off);
+                  gload16(rr[bank * RQ + i], rrow + (int64_t)(ri + 3 + i) * RPP * g.ldr, rlane);
+                  gload16(rr[bank * RQ + 2 + i], rrow + (int64_t)(ri + 3 + i) * RPP * g.ldr + g.gate_off, rlane);
                 }
               }
               u4v_t pg;
@@ -828,7 +894,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
             if (RES_FAST && res_fast) {
               constexpr int IPM = 16 / RPP;                 // store instructions per 16-row fragment
               const int ri = mi * IPM + it;                 // index of this store = index of its residual load
-              const int bank = (ri / RQ) & 1;
+              const int bank = RES_FULL ? ri / RQ : (ri / RQ) & 1;
+              if constexpr (RES_FULL) {
+                if (ri % RQ == 0) {
+                  // batch b = ri/RQ: behind it went the later batches and the stores so far (and, behind batch
+                  // 0, the prefetch): 3 RQ - b RQ + ri = 3 RQ requests
+                  static_assert(!RES_FULL || RQ == 4, "four batches of four");
+                  batch_wait(3 * RQ, ri == 0);
+                  asm volatile("" : "+v"(rr[bank * RQ]), "+v"(rr[bank * RQ + 1]), "+v"(rr[bank * RQ + 2]), "+v"(rr[bank * RQ + 3]));
+                }
+              }
               const u4v_t rv = rr[bank * RQ + ri % RQ];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -836,10 +911,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
                 o8[2 * j + 1] += __uint_as_float(rv[j] & 0xffff0000u);
               }
               // the bank just emptied takes the batch after next (issued after this batch's last use)
-              if (ri % RQ == RQ - 1 && ri + 1 + RQ < 2 * MI) {
+              if (!RES_FULL && ri % RQ == RQ - 1 && ri + 1 + RQ < 2 * MI) {
 #pragma unroll
                 for (int i = 0; i < RQ; ++i)
-                  rr[bank * RQ + i] = *reinterpret_cast<const u4v_t *>(rrow + (int64_t)(ri + 1 + RQ + i) * RPP * g.ldr);
+                  rr[bank * RQ + i] = *reinterpret_cast<const u4v_t *>((const char *)(rrow + (int64_t)(ri + 1 + RQ + i) * RPP * g.ldr) + rlane);
               }
             }
             // non-temporal: the tile is not read again by this kernel, and keeping it out of the
@@ -1079,7 +1154,12 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
   if (out_dtype == LDM_BF16) {
     // projection + bias + residual (out-projection, MLP down-projection): the kernel variant whose
     // epilogue streams the residual rows in around the next tile's prefetch
-    if (!use128 && R && akc && bkc && ldr % 8 == 0 && ldc % 8 == 0) return launch256<true, true, 256, bf16_t, 0, 1>(g, s);
+    if (!use128 && R && akc && bkc && ldr % 8 == 0 && ldc % 8 == 0) {
+      // every tile full and aligned: the variant with nothing but the streaming epilogue
+      if (M % 256 == 0 && N % 256 == 0 && ldr < (1 << 27) && aligned_to(C, 16) && aligned_to(R, 16) && !g.row_map)
+        return launch256<true, true, 256, bf16_t, 0, 5>(g, s);
+      return launch256<true, true, 256, bf16_t, 0, 1>(g, s);
+    }
     return use128 ? dispatch_layout<128, bf16_t, 0>(g, akc, bkc, s) : dispatch_layout<256, bf16_t, 0>(g, akc, bkc, s);
   }
   if (out_dtype == LDM_F32)
@@ -1099,6 +1179,7 @@ int ldm_gemm_mfma256_bf16_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void
   const int rc = fill(g, 0, 0, T, F, K, 1.0f, dy, ld_dy, W, ldw, dag, ld_dag, nullptr, ag, ld_ag);
   if (rc) return rc;
   if (T < 256 || T % 256 || F < 256 || F % 256) return LDM_E_SHAPE;
+  if (ld_ag >= (1 << 27)) return LDM_E_SHAPE;   // (the epilogue's per-lane byte offsets into ag are 32-bit)
   if (ld_ag % 8 || ld_dag % 8 || ld_ag < 2 * F || ld_dag < 2 * F || !aligned_to(ag, 16) || !aligned_to(dag, 16)) return LDM_E_ALIGN;
   const int64_t tm = T / 256, tn = F / 256;
   if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
