@@ -199,6 +199,10 @@ __device__ __forceinline__ void gload16(u4g_t &v, const void *sbase, unsigned la
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(sbase) : "memory");
 }
 
+__device__ __forceinline__ void gload4(unsigned &v, const void *sbase, unsigned lane_off) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(sbase) : "memory");
+}
+
 // 16 rows x 32 k fragment of a K-contiguous half-tile image (64-byte rows)
 __device__ __forceinline__ bf8_t read_frag_kc(const char *img, int rbase, int lane) {
   const int r = rbase + (lane & 15);
@@ -386,43 +390,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     constexpr int CPL = sizeof(TO) == 2 ? 8 : 4;
     constexpr int LPR = 64 / CPL;         // lanes per row
     constexpr int RPP = 64 / LPR;         // rows per store instruction
-    // bias of this lane's output columns; the empty asm is a use, so the compiler's wait for
-    // the load sits HERE (it drains the three half-tiles in flight, which are needed next
-    // anyway) and not inside the epilogue, where it would drain the next item's prefetch.
-    float bv[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) bv[j] = 0.f;
-    if (EPI == 0 && RES != 4 && g.bias) {
-      const int64_t n = nw + (lane % LPR) * CPL;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j)
-        if (n + j < g.N) bv[j] = g.bias[n + j];
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) asm volatile("" : "+v"(bv[j]));
-    }
-
-    // RES 3: biases of this lane's accumulator columns (fragments 0-1: a, 2-3: g of the same hidden columns)
-    f4_t bag[(RES == 3 || RES == 4) ? 4 : 1];
-    if (RES == 4) {   // biases of this lane's accumulator columns (4 consecutive ones per fragment)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bag[i] = f4_t{0.f, 0.f, 0.f, 0.f};
-        if (g.bias) bag[i] = *reinterpret_cast<const f4_t *>(g.bias + rope_group_col(tid.tn, wn * 4 + i, g.rope_D, g.rope_hd) + (lane >> 4) * 4);
-        asm volatile("" : "+v"(bag[i]));
-      }
-    }
-    if (RES == 3) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bag[i] = f4_t{0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
-          const int64_t hc = (int64_t)tid.tn * (BN / 2) + wn * 32 + (i & 1) * 16 + (lane >> 4) * 4 + (i >> 1) * g.gate_off;
-          bag[i] = *reinterpret_cast<const f4_t *>(g.bias + hc);
-        }
-        asm volatile("" : "+v"(bag[i]));
-      }
-    }
-
     f4_t acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -651,6 +618,46 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       }
     }
 
+    // Bias of this lane's output columns (RES 3 / 4: of its accumulator columns, 4 consecutive ones per
+    // fragment; RES 3: fragments 0-1 a, 2-3 g of the same hidden columns).  Requested HERE -- nothing else is
+    // in flight -- and waited for, counted, behind the next item's prefetch.  (Loaded at the top of the item
+    // with the compiler's waits, every item began with vmcnt(0) -- for the previous item's stores, which the
+    // first phases are meant to overlap, and the prefetch -- once per load: five round trips in RES 3 / 4.)
+    // Without a bias there are neither loads nor a wait; a column past N reads the last one (a fixed number
+    // of loads for the counted waits).
+    constexpr int NBIAS = EPI != 0 ? 0 : (RES == 3 || RES == 4) ? 4 : CPL;
+    float bv[CPL];
+    f4_t bag[(RES == 3 || RES == 4) ? 4 : 1];
+    [[maybe_unused]] unsigned bvr[CPL] = {};
+    [[maybe_unused]] u4g_t bagr[(RES == 3 || RES == 4) ? 4 : 1] = {};
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) bv[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < ((RES == 3 || RES == 4) ? 4 : 1); ++i) bag[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+    if (NBIAS > 0 && g.bias) {
+      const void *bsrc = g.bias;
+      if constexpr (RES == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t c = rope_group_col(tid.tn, wn * 4 + i, g.rope_D, g.rope_hd) + (lane >> 4) * 4;
+          gload16(bagr[i], bsrc, (unsigned)(c * 4));
+        }
+      } else if constexpr (RES == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t hc = (int64_t)tid.tn * (BN / 2) + wn * 32 + (i & 1) * 16 + (lane >> 4) * 4 + (i >> 1) * g.gate_off;
+          gload16(bagr[i], bsrc, (unsigned)(hc * 4));
+        }
+      } else {
+        const int64_t n = nw + (lane % LPR) * CPL;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const int64_t c = n + j < g.N ? n + j : g.N - 1;
+          gload4(bvr[j], bsrc, (unsigned)(c * 4));
+        }
+      }
+    }
+
     [[maybe_unused]] const int tid_cur_tn = tid.tn;
     // RES 4: bias, then (on the q and k tiles) the rotary embedding of src/transformer.py:178-185 with
     // the query scale of :261 folded in: fragments ni and ni + 2 hold x[d] and x[d + hd/2] of the same row.
@@ -673,11 +680,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int d = rope_group_d(tid.tn, wn, ni, g.rope_D, g.rope_hd) + (lane >> 4) * 4;
-          rcs[ni] = *reinterpret_cast<const f4_t *>(g.rope_cos + (int64_t)pos * h2 + d) * sc;
-          rsn[ni] = *reinterpret_cast<const f4_t *>(g.rope_sin + (int64_t)pos * h2 + d) * sc;
+          rcs[ni] = *reinterpret_cast<const f4_t *>(g.rope_cos + (int64_t)pos * h2 + d);
+          rsn[ni] = *reinterpret_cast<const f4_t *>(g.rope_sin + (int64_t)pos * h2 + d);
           rstc[ni] = *reinterpret_cast<const f4_t *>(g.rope_step + d);
           rsts[ni] = *reinterpret_cast<const f4_t *>(g.rope_step + h2 + d);
         }
+        // (all eight requested before the first is used: one round trip, not one per pair)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) { rcs[ni] = rcs[ni] * sc; rsn[ni] = rsn[ni] * sc; }
       }
     }
     w += gridDim.x;
@@ -705,6 +715,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
       else stage_ptrs<B_KC, BN>(baseB, g.ldb, (int64_t)tid.tn * (RES == 3 ? BN / 2 : BN), g.N, wave, lane_t, srcB,
                                 RES == 3 ? g.gate_off : 0);
       issue_first();
+    }
+    // (without a bias nothing was requested and the wait passes at once; the plain and SwiGLU-backward
+    // variants, whose callers mostly have none, skip it then: with it their input-gradient GEMMs are 1 % slower)
+    if (NBIAS > 0 && ((RES != 0 && RES != 2) || g.bias)) {
+      // younger than the bias loads: the first residual batch of the asm-reading variants and the prefetch
+      // (anything the compiler has put between them only makes the wait stricter)
+      constexpr int NPF0 = 2 * PI + 3 * SI;
+      constexpr int NL0 = (RES == 2 || RES == 5) ? 4 : 0;
+      if (more && np > 0) wait_vm<NPF0 + NL0>(); else wait_vm<NL0>();
+      if constexpr (RES == 3 || RES == 4) {
+        asm volatile("" : "+v"(bagr[0]), "+v"(bagr[1]), "+v"(bagr[2]), "+v"(bagr[3]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bag[i] = g.bias ? __builtin_bit_cast(f4_t, bagr[i]) : f4_t{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int64_t n = nw + (lane % LPR) * CPL;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          asm volatile("" : "+v"(bvr[j]));
+          bv[j] = (g.bias && n + j < g.N) ? __uint_as_float(bvr[j]) : 0.f;
+        }
+      }
     }
 
     if (EPI == 1 && do_rowsum && lane < 16) {
