@@ -511,6 +511,8 @@ def test_gemm_persistent_many_tiles(dev, tb, M, N, K):
     assert rel_err(c.float(), ref + bias.double()) < 4e-3
     c = _gemm_call(a, b, 0, tb, M, N, K, torch.bfloat16, bias, res)
     assert rel_err(c.float(), ref + bias.double() + res.double()) < 4e-3
+    c = _gemm_call(a, b, 0, tb, M, N, K, torch.bfloat16, None, res)     # residual without bias
+    assert rel_err(c.float(), ref + res.double()) < 4e-3
     c = _gemm_call(a, b, 0, tb, M, N, K, torch.float32, bias)
     assert rel_err(c, ref + bias.double()) < 1e-5
 
