@@ -50,4 +50,11 @@ def keep_mask(p: float, seed: int, n_bh: int, seq_q: int, seq_k: int, bh0: int =
     k = np.arange(seq_k, dtype=np.uint64)[None, None, :]
     bhkey = mix32((lo + bh * np.uint64(0x9E3779B1)) & M32)
     rowkey = mix32(bhkey ^ ((hi + q * np.uint64(0x85EBCA77)) & M32))
-    return mix32((rowkey + k * np.uint64(0xC2B2AE3D)) & M32) >= thr
+    return keep_step(rowkey, k) >= thr
+
+
+def keep_step(rowkey, k):
+    """ldm_drop_keep's value: one xorshift and one 24 x 24 -> 32 bit multiply of rowkey + k * C."""
+    x = (np.asarray(rowkey, dtype=np.uint64) + np.asarray(k, dtype=np.uint64) * np.uint64(0x5ED85E17)) & M32
+    a = (x ^ (x >> np.uint64(13))) & np.uint64(0xFFFFFF)
+    return (a * np.uint64(0xCB5E35)) & M32
