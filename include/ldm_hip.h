@@ -250,6 +250,16 @@ int ldm_attn_bwd_dropout(int dtype, const void *qkv, int64_t ld_qkv, const uint8
  * slot fixed at 0xffffffff: regenerated, never stored.  p in [0, 1). */
 int ldm_dropout_add(const void *y, const void *res, void *out, int64_t rows, int64_t d, int dtype,
                     float p, uint64_t seed, void *stream);
+/* The same line of the encoder layer with its projection (src/transformer.py:352 with :288, :361 with
+ * :95): C[M, N] = R + keep * (A[M, K] W[N, K]^T + bias) / (1 - p) from ONE GEMM, the mask applied in the
+ * epilogue before the residual joins.  keep(row, col) is that of ldm_dropout_add with the same p and seed,
+ * so the backward is ldm_dropout_add(g, NULL, ...) followed by the projection's usual backward.  BF16; A,
+ * W K-contiguous; M and N multiples of 256, row strides multiples of 8, C and R 16-byte aligned, bias
+ * fp32 [N] or NULL; otherwise LDM_E_SHAPE / LDM_E_ALIGN (the caller then runs ldm_gemm and
+ * ldm_dropout_add). */
+int ldm_gemm_dropout_residual(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *W,
+                              int64_t ldw, const float *bias, const void *R, int64_t ldr, void *C, int64_t ldc,
+                              float p, uint64_t seed, void *stream);
 
 /* ---------------------------------------------------------------- K4: masked cross-entropy
  * masked_cross_entropy_loss / variational_lower_bound_loss (src/loss.py:8-65).

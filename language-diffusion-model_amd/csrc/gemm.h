@@ -35,6 +35,10 @@ int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, 
 int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                                    const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc,
                                    const int *dyn_k, float *rowsum, hipStream_t s);
+// residual + dropout(projection + bias) from one GEMM (full, aligned 256 x 256 tiles only)
+int ldm_gemm_mfma256_bf16_drop_res(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *W,
+                                   int64_t ldw, void *C, int64_t ldc, const float *bias, const void *R, int64_t ldr,
+                                   unsigned thresh, float inv, uint64_t seed, hipStream_t s);
 // SwiGLU backward fused into the down-projection's input-gradient GEMM (full 256 x 256 tiles only)
 int ldm_gemm_mfma256_bf16_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
                                      int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag,

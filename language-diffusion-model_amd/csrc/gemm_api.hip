@@ -95,6 +95,18 @@ extern "C" int ldm_gemm_batched(int in_dtype, int out_dtype, int transA, int tra
                           sc, nullptr, nullptr, 0, batch, batch_inner, (hipStream_t)stream);
 }
 
+extern "C" int ldm_gemm_dropout_residual(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *W,
+                                         int64_t ldw, const float *bias, const void *R, int64_t ldr, void *C,
+                                         int64_t ldc, float p, uint64_t seed, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !R || !C || !(p >= 0.0f) || !(p < 1.0f)) return LDM_E_BADARG;
+  // threshold and scale exactly as ldm_dropout_add derives them
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  const float inv = (float)(4294967296.0 / (4294967296.0 - (double)thresh));
+  return ldm_gemm_mfma256_bf16_drop_res(M, N, K, A, lda, W, ldw, C, ldc, bias, R, ldr, thresh, inv, seed,
+                                        (hipStream_t)stream);
+}
+
 extern "C" int ldm_gemm_swiglu_bwd(int64_t T, int64_t F, int64_t K, const void *dy, int64_t ld_dy, const void *W,
                                    int64_t ldw, const void *ag, int64_t ld_ag, void *dag, int64_t ld_dag,
                                    void *stream) {
@@ -119,7 +131,7 @@ extern "C" int ldm_gemm_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, in
                                         ld_qkv, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 14; }
+extern "C" int ldm_abi_version(void) { return 15; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

@@ -59,6 +59,8 @@ struct MArgs {
   int64_t gate_off;   // RES 2: columns of the gate half in R and C (R = [a | g], C = [da | dg])
                       // RES 3: rows of the gate weights in B = [w1; w2] and columns of g in C = [a | g]
   void *C2; int64_t ldc2;   // RES 3: h = a * silu(g), [M, gate_off]
+  // RES 5: dropout of the product (+ bias) before the residual is added; drop_thresh == 0: none
+  unsigned drop_thresh, drop_lo, drop_hi; float drop_inv;
   // RES 4 (q/k/v projection with the rotary embedding in the epilogue): fp32 tables [rope_S, rope_hd/2],
   // rope_step = [cos(16 theta_d) | sin(16 theta_d)] (2 x rope_hd/2), rope_D = H * hd columns per third
   const float *rope_cos, *rope_sin, *rope_step;
@@ -578,46 +580,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // All reads of the ring are complete for every wave (lgkmcnt(0) before each barrier) and
     // no LDS-DMA is outstanding: slots 0-3 can take the next item's first half-tiles now.
 
-    // Fast-path epilogue with a residual (bf16 output): the residual rows of this wave's tile are
-    // loaded 16 bytes per lane exactly where the stores will go, in batches of RQ loads held in two
-    // register banks: batch 0 is issued HERE, before the next item's LDS-DMA prefetch (so its
-    // latency runs under the prefetch set-up), batch k+2 as soon as batch k has been consumed.
-    constexpr bool RES_FAST = (RES == 1 || RES == 5) && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
-    // RES 5: RES 1 for a problem whose every tile is full and aligned and has a residual (the host checks): no
-    // other epilogue is compiled into the variant, which leaves the registers for residual loads written as
-    // asm with counted waits
-    constexpr bool RES_FULL = RES == 5;
-    static_assert(!RES_FULL || RES_FAST, "RES 5 is a 256-column bf16 variant");
-    // RES 2: C = [dh * silu(g) | dh * a * silu'(g)] with dh the product and [a | g] read from R (SwiGLU backward)
-    constexpr bool SWI_FAST = RES == 2 && EPI == 0 && sizeof(TO) == 2 && MI == 8;
-    typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
-    const bool fast_tile = RES_FULL || (EPI == 0 && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0);
-    const bool res_fast = RES_FULL || (RES_FAST && fast_tile && g.R != nullptr && (g.ldr % CPL) == 0 && g.ldr < (1 << 27));   // (32-bit lane offset)
-    // RQ loads (a quarter of the tile's 2 MI store positions) per batch, two batches in registers
-    constexpr int RQ = MI / 2;
-    // RES 5 holds the residual of the whole tile (four batches, all requested before the first is used)
-    u4v_t rr[RES_FULL ? 4 * RQ : (RES_FAST || SWI_FAST) ? 2 * RQ : 1];   // SWI: per bank (a0, a1, g0, g1) of two store positions
-    const TO *rrow = nullptr;        // wave-uniform: the wave's first row of R at its first column
-    int lane_e = lane;
-    if constexpr (RES == 1) asm volatile("" : "+v"(lane_e));   // (not kept across the main loop either)
-    [[maybe_unused]] const unsigned rlane = (unsigned)(((lane_e / LPR) * g.ldr + (lane_e % LPR) * CPL) * sizeof(TO));
-    if (SWI_FAST) {
-      rrow = (const TO *)g.R + (m0 + wm * (MI * 16)) * g.ldr + nw;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        gload16(rr[i], rrow + (int64_t)i * RPP * g.ldr, rlane);
-        gload16(rr[2 + i], rrow + (int64_t)i * RPP * g.ldr + g.gate_off, rlane);
-      }
-    }
-    if (RES_FAST && res_fast) {
-      rrow = (const TO *)g.R + (m0 + wm * (MI * 16)) * g.ldr + nw;
-#pragma unroll
-      for (int i = 0; i < RQ; ++i) {
-        if constexpr (RES_FULL) gload16(rr[i], rrow + (int64_t)i * RPP * g.ldr, rlane);
-        else rr[i] = *reinterpret_cast<const u4v_t *>((const char *)(rrow + (int64_t)i * RPP * g.ldr) + rlane);
-      }
-    }
-
     // Bias of this lane's output columns (RES 3 / 4: of its accumulator columns, 4 consecutive ones per
     // fragment; RES 3: fragments 0-1 a, 2-3 g of the same hidden columns).  Requested HERE -- nothing else is
     // in flight -- and waited for, counted, behind the next item's prefetch.  (Loaded at the top of the item
@@ -655,6 +617,46 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
           const int64_t c = n + j < g.N ? n + j : g.N - 1;
           gload4(bvr[j], bsrc, (unsigned)(c * 4));
         }
+      }
+    }
+
+    // Fast-path epilogue with a residual (bf16 output): the residual rows of this wave's tile are
+    // loaded 16 bytes per lane exactly where the stores will go, in batches of RQ loads held in two
+    // register banks: batch 0 is issued HERE, before the next item's LDS-DMA prefetch (so its
+    // latency runs under the prefetch set-up), batch k+2 as soon as batch k has been consumed.
+    constexpr bool RES_FAST = (RES == 1 || RES == 5) && EPI == 0 && sizeof(TO) == 2 && MI == 8;   // 256-column tiles, bf16 output
+    // RES 5: RES 1 for a problem whose every tile is full and aligned and has a residual (the host checks): no
+    // other epilogue is compiled into the variant, which leaves the registers for residual loads written as
+    // asm with counted waits
+    constexpr bool RES_FULL = RES == 5;
+    static_assert(!RES_FULL || RES_FAST, "RES 5 is a 256-column bf16 variant");
+    // RES 2: C = [dh * silu(g) | dh * a * silu'(g)] with dh the product and [a | g] read from R (SwiGLU backward)
+    constexpr bool SWI_FAST = RES == 2 && EPI == 0 && sizeof(TO) == 2 && MI == 8;
+    typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+    const bool fast_tile = RES_FULL || (EPI == 0 && !g.row_map && m0 + BM <= Mdyn && n0 + BN <= g.N && (g.ldc % CPL) == 0);
+    const bool res_fast = RES_FULL || (RES_FAST && fast_tile && g.R != nullptr && (g.ldr % CPL) == 0 && g.ldr < (1 << 27));   // (32-bit lane offset)
+    // RQ loads (a quarter of the tile's 2 MI store positions) per batch, two batches in registers
+    constexpr int RQ = MI / 2;
+    // RES 5 holds the residual of the whole tile (four batches, all requested before the first is used)
+    u4v_t rr[RES_FULL ? 4 * RQ : (RES_FAST || SWI_FAST) ? 2 * RQ : 1];   // SWI: per bank (a0, a1, g0, g1) of two store positions
+    const TO *rrow = nullptr;        // wave-uniform: the wave's first row of R at its first column
+    int lane_e = lane;
+    if constexpr (RES == 1) asm volatile("" : "+v"(lane_e));   // (not kept across the main loop either)
+    [[maybe_unused]] const unsigned rlane = (unsigned)(((lane_e / LPR) * g.ldr + (lane_e % LPR) * CPL) * sizeof(TO));
+    if (SWI_FAST) {
+      rrow = (const TO *)g.R + (m0 + wm * (MI * 16)) * g.ldr + nw;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        gload16(rr[i], rrow + (int64_t)i * RPP * g.ldr, rlane);
+        gload16(rr[2 + i], rrow + (int64_t)i * RPP * g.ldr + g.gate_off, rlane);
+      }
+    }
+    if (RES_FAST && res_fast) {
+      rrow = (const TO *)g.R + (m0 + wm * (MI * 16)) * g.ldr + nw;
+#pragma unroll
+      for (int i = 0; i < RQ; ++i) {
+        if constexpr (RES_FULL) gload16(rr[i], rrow + (int64_t)i * RPP * g.ldr, rlane);
+        else rr[i] = *reinterpret_cast<const u4v_t *>((const char *)(rrow + (int64_t)i * RPP * g.ldr) + rlane);
       }
     }
 
@@ -719,8 +721,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
     // (without a bias nothing was requested and the wait passes at once; the plain and SwiGLU-backward
     // variants, whose callers mostly have none, skip it then: with it their input-gradient GEMMs are 1 % slower)
     if (NBIAS > 0 && ((RES != 0 && RES != 2) || g.bias)) {
-      // younger than the bias loads: the first residual batch of the asm-reading variants and the prefetch
-      // (anything the compiler has put between them only makes the wait stricter)
+      // younger than the bias loads (which go out first of all): the first residual batch of the
+      // asm-reading variants and the prefetch (anything the compiler has put between them only makes the
+      // wait stricter)
       constexpr int NPF0 = 2 * PI + 3 * SI;
       constexpr int NL0 = (RES == 2 || RES == 5) ? 4 : 0;
       if (more && np > 0) wait_vm<NPF0 + NL0>(); else wait_vm<NL0>();
@@ -921,6 +924,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(MArgs g) {
               pg[2] = pack_bf16x2(dg8[4], dg8[5]);
               pg[3] = pack_bf16x2(dg8[6], dg8[7]);
               __builtin_nontemporal_store(pg, reinterpret_cast<u4v_t *>(crow + g.gate_off));
+            }
+            if constexpr (RES_FULL) {
+              // residual dropout (src/transformer.py:352,361: src + self.dropout(sublayer)): the mask of
+              // ldm_dropout_add -- keep(row, column) of common.h in the 0xffffffff stream -- on the product
+              // + bias, before the residual joins
+              if (g.drop_thresh) {
+                const unsigned row = (unsigned)(m0 + wm * (MI * 16) + mi * 16 + it * RPP + lane / LPR);
+                const unsigned rk = ldm_drop_row(ldm_drop_bh(g.drop_lo, 0xffffffffu), g.drop_hi, row);
+                const unsigned c0 = (unsigned)(nw + cl * CPL);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = ldm_drop_keep(rk, c0 + j, g.drop_thresh) ? o8[j] * g.drop_inv : 0.f;
+              }
             }
             if (RES_FAST && res_fast) {
               constexpr int IPM = 16 / RPP;                 // store instructions per 16-row fragment
@@ -1141,6 +1156,7 @@ int fill(MArgs &g, int transA, int transB, int64_t M, int64_t N, int64_t K, floa
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
   g.gate_off = 0;
+  g.drop_thresh = g.drop_lo = g.drop_hi = 0; g.drop_inv = 1.0f;
   g.C2 = nullptr; g.ldc2 = 0;
   g.rope_cos = g.rope_sin = g.rope_step = nullptr; g.rope_hd = 0; g.rope_S = 0; g.rope_D = 0; g.rope_qscale = 1.0f;
   g.splits = 1;
@@ -1196,6 +1212,27 @@ int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int6
   if (out_dtype == LDM_F32)
     return use128 ? dispatch_layout<128, float, 0>(g, akc, bkc, s) : dispatch_layout<256, float, 0>(g, akc, bkc, s);
   return LDM_E_DTYPE;
+}
+
+// C[M, N] = R + dropout(A[M, K] * W[N, K]^T + bias) (src/transformer.py:352,361 around the out- and the
+// down-projection): the residual-dropout mask of ldm_dropout_add applied in the epilogue of the RES 5
+// variant.  Only what that variant takes (bf16, every tile full and aligned); otherwise LDM_E_SHAPE /
+// LDM_E_ALIGN and the caller runs ldm_gemm and ldm_dropout_add.
+int ldm_gemm_mfma256_bf16_drop_res(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *W,
+                                   int64_t ldw, void *C, int64_t ldc, const float *bias, const void *R, int64_t ldr,
+                                   unsigned thresh, float inv, uint64_t seed, hipStream_t s) {
+  MArgs g;
+  const int rc = fill(g, 0, 1, M, N, K, 1.0f, A, lda, W, ldw, C, ldc, bias, R, ldr);
+  if (rc) return rc;
+  if (M < 256 || M % 256 || N < 256 || N % 256 || M > 0xffffffffll || ldr >= (1 << 27)) return LDM_E_SHAPE;
+  if (!R || ldr % 8 || ldc % 8 || !aligned_to(C, 16) || !aligned_to(R, 16)) return LDM_E_ALIGN;
+  const int64_t tm = M / 256, tn = N / 256;
+  if (tm * tn > 0x3fffffff) return LDM_E_SHAPE;
+  g.tiles_m = (int)tm;
+  g.tiles_n = (int)tn;
+  g.drop_thresh = thresh; g.drop_inv = inv;
+  g.drop_lo = (unsigned)seed; g.drop_hi = (unsigned)(seed >> 32);
+  return launch256<true, true, 256, bf16_t, 0, 5>(g, s);
 }
 
 // dag[T, 2F] = [ dh * silu(g) | dh * a * silu'(g) ] with dh = dy[T, K] * W[K, F] never written to memory:

@@ -195,6 +195,52 @@ def _gemm(in_dt, out_dt, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, res
                                  N.ptr(bias), N.ptr(res), ldr, N.stream()), "ldm_gemm")
 
 
+FUSED_RESIDUAL_DROPOUT = os.environ.get("LDM_FUSED_RES_DROPOUT", "1") != "0"   # residual dropout inside the projection's epilogue
+
+
+def _draw_seed() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _project_residual(dt, T, n_pad, k, a, lda, w, y, b, res, drop):
+    """y[T, n_pad] = res + dropout(a @ w^T + b): the `src + self.dropout(sublayer(...))` lines of the
+    reference layer (src/transformer.py:352,361) with the sublayer's last projection.  ``drop`` = (p, seed)
+    or None (plain residual add in the GEMM epilogue).  One GEMM where the kernel takes the shape
+    (ldm_gemm_dropout_residual); otherwise the projection and ldm_dropout_add, same mask."""
+    ldr = res.stride(0) if res is not None else 0
+    if drop is None:
+        _gemm(dt, dt, 0, 1, T, n_pad, k, a, lda, w, k, y, n_pad, bias=b, res=res, ldr=ldr, tag="gemm.fwd")
+        return
+    p, seed = drop
+    rc = -3
+    if FUSED_RESIDUAL_DROPOUT and dt == torch.bfloat16 and res is not None:
+        with _Timed("gemm.fwd", 2.0 * T * n_pad * k):
+            rc = N.lib().ldm_gemm_dropout_residual(T, n_pad, k, a.data_ptr(), lda, w.data_ptr(), k, N.ptr(b),
+                                                   res.data_ptr(), ldr, y.data_ptr(), n_pad, float(p), int(seed), N.stream())
+        if rc not in (-2, -3):
+            N.check(rc, "ldm_gemm_dropout_residual")
+    if rc in (-2, -3):
+        _gemm(dt, dt, 0, 1, T, n_pad, k, a, lda, w, k, y, n_pad, bias=b, tag="gemm.fwd")
+        rc_ = res if (res is None or (res.is_contiguous() and res.shape[1] == n_pad)) else None
+        if res is not None and rc_ is None:     # a residual narrower than the padded row, or strided
+            rc_ = torch.zeros(T, n_pad, dtype=dt, device=y.device)
+            rc_[:, :res.shape[1]].copy_(res)
+        N.check(N.lib().ldm_dropout_add(y.data_ptr(), N.ptr(rc_), y.data_ptr(), T, n_pad, N.dtype_code(dt), float(p),
+                                        int(seed), N.stream()), "ldm_dropout_add")
+
+
+def _drop_grad(g, drop):
+    """Gradient w.r.t. the projection output under the residual dropout: keep * g / (1 - p), same mask."""
+    if drop is None:
+        return g
+    p, seed = drop
+    gc_ = g if g.is_contiguous() else g.contiguous()
+    out = torch.empty_like(gc_)
+    N.check(N.lib().ldm_dropout_add(gc_.data_ptr(), None, out.data_ptr(), gc_.shape[0], gc_.shape[1],
+                                    N.dtype_code(gc_.dtype), float(p), int(seed), N.stream()), "ldm_dropout_add(backward)")
+    return out
+
+
 def _weight_bias_grads(pack, g, x_in, ld_x, T, k, dev, dt):
     """dW [n_pad, k] and db [n_pad] of a projection from its output gradient g [T, n_pad] and its input
     (one zeroed buffer; for bf16 one kernel produces both), split per packed parameter."""
@@ -248,7 +294,7 @@ class _PackedLinear(torch.autograd.Function):
     attention backward hands back the gradient w.r.t. the projection output BEFORE the rotation."""
 
     @staticmethod
-    def forward(ctx, x2, residual, pack: PackedWeights, link, rope, *params):
+    def forward(ctx, x2, residual, pack: PackedWeights, link, rope, drop, *params):
         N.require_device(x2)
         w, b = pack.get()
         T, k = x2.shape
@@ -273,8 +319,8 @@ class _PackedLinear(torch.autograd.Function):
                 N.check(rc, "ldm_gemm_qkv_rope")
                 rope.applied = True
         if rc in (-2, -3):
-            _gemm(dt, dt, 0, 1, T, pack.n_pad, k, x2, x2.stride(0), w, k, y, pack.n_pad, bias=b,
-                  res=res, ldr=res.stride(0) if res is not None else 0, tag="gemm.fwd")
+            _project_residual(dt, T, pack.n_pad, k, x2, x2.stride(0), w, y, b, res, drop)
+        ctx.drop = drop
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.save_for_backward(x2, w)
@@ -317,13 +363,14 @@ class _PackedLinear(torch.autograd.Function):
         else:
             g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
             g[:, :n].copy_(gy)
+        g = _drop_grad(g, ctx.drop)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, k, dtype=dt, device=g.device)
             _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
         grads_w, grads_b = _weight_bias_grads(pack, g, x2, x2.stride(0), T, k, g.device, dt)
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
-        return (dx, dres, None, None, None, *grads_w, *grads_b)
+        return (dx, dres, None, None, None, None, *grads_w, *grads_b)
 
 
 def _backward_compact(ctx, x2, w, dlc, rows, count):
@@ -366,17 +413,20 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
         grads_b.append(db[off:off + ne])
         off += ne
     COMPACT_STATS["used"] += 1
-    return (dx, None, None, None, None, *grads_w, *grads_b)
+    return (dx, None, None, None, None, None, *grads_w, *grads_b)
 
 
 _PackedLinear._backward_compact = staticmethod(_backward_compact)
 
 
-def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None, rope: RopeSpec | None = None) -> Tensor:
+def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None, rope: RopeSpec | None = None,
+                  residual_dropout: float = 0.0) -> Tensor:
+    """``residual_dropout`` p > 0 (with a residual): residual + dropout(projection, p), training semantics."""
     shape = x.shape
     x2 = _rows2d(x)
     link = _HeadLink() if pack.compact_rows else None
-    y = _PackedLinear.apply(x2, residual, pack, link, rope, *pack.weights, *pack.biases)
+    drop = (float(residual_dropout), _draw_seed()) if (residual is not None and residual_dropout > 0.0) else None
+    y = _PackedLinear.apply(x2, residual, pack, link, rope, drop, *pack.weights, *pack.biases)
     out = y.reshape(*shape[:-1], pack.n) if y.is_contiguous() else y.view(*shape[:-1], pack.n)
     if link is not None:
         out._ldm_head_link = link    # read by masked_ce when THIS tensor object is handed to the loss
@@ -620,7 +670,7 @@ class _SwiGLUDown(torch.autograd.Function):
     out of the epilogue of the GEMM dy @ W3 (ldm_gemm_swiglu_bwd)."""
 
     @staticmethod
-    def forward(ctx, ag, h, residual, pack: PackedWeights, *params):
+    def forward(ctx, ag, h, residual, pack: PackedWeights, drop, *params):
         N.require_device(ag)
         lib = N.lib()
         w, b = pack.get()
@@ -642,8 +692,8 @@ class _SwiGLUDown(torch.autograd.Function):
             res = _rows2d(residual)
             if res.dtype != dt:
                 res = res.to(dt)
-        _gemm(dt, dt, 0, 1, T, pack.n_pad, F, h, F, w, F, y, pack.n_pad, bias=b, res=res,
-              ldr=res.stride(0) if res is not None else 0, tag="gemm.fwd")
+        _project_residual(dt, T, pack.n_pad, F, h, F, w, y, b, res, drop)
+        ctx.drop = drop
         ctx.pack = pack
         ctx.res_shape = tuple(residual.shape) if residual is not None else None
         ctx.out_shape = tuple(ag.shape[:-1]) + (pack.n,)
@@ -666,6 +716,7 @@ class _SwiGLUDown(torch.autograd.Function):
         else:
             g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
             g[:, :n].copy_(gy2)
+        g = _drop_grad(g, ctx.drop)
         dag = None
         if ctx.needs_input_grad[0]:
             dag = torch.empty_like(ag2)
@@ -684,14 +735,17 @@ class _SwiGLUDown(torch.autograd.Function):
             dag = dag.view(ctx.ag_shape)
         grads_w, grads_b = _weight_bias_grads(pack, g, h, F, T, F, g.device, dt)
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
-        return (dag, None, dres, None, grads_w[0], grads_b[0])
+        return (dag, None, dres, None, None, grads_w[0], grads_b[0])
 
 
-def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None, h: Tensor | None = None) -> Tensor:
+def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None, h: Tensor | None = None,
+                residual_dropout: float = 0.0) -> Tensor:
     """w3(a * silu(g)) (+ residual) for the fused activation ag = [a | g]; one weight in ``pack``.
-    ``h``: a * silu(g) if the caller has it (the second output of swiglu_up)."""
+    ``h``: a * silu(g) if the caller has it (the second output of swiglu_up).  ``residual_dropout`` p > 0
+    (with a residual): residual + dropout(w3(...), p)."""
     assert len(pack.weights) == 1
-    return _SwiGLUDown.apply(ag, h, residual, pack, pack.weights[0], pack.biases[0])
+    drop = (float(residual_dropout), _draw_seed()) if (residual is not None and residual_dropout > 0.0) else None
+    return _SwiGLUDown.apply(ag, h, residual, pack, drop, pack.weights[0], pack.biases[0])
 
 
 # ----------------------------------------------------------------------------

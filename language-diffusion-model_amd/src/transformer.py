@@ -96,9 +96,9 @@ class SwiGLU(nn.Module):
                 self._packs[key] = ops.PackedWeights([self.w3.weight], [self.w3.bias], self.compute_dtype, "w3")
         return self._packs[key]
 
-    def forward(self, x: Tensor, residual: Tensor | None = None) -> Tensor:
+    def forward(self, x: Tensor, residual: Tensor | None = None, residual_dropout: float = 0.0) -> Tensor:
         ag, h = ops.swiglu_up(x, self._pack("in"))      # h = a * silu(g) out of the same GEMM's epilogue
-        return ops.swiglu_down(ag, self._pack("out"), residual=residual, h=h)
+        return ops.swiglu_down(ag, self._pack("out"), residual=residual, h=h, residual_dropout=residual_dropout)
 
 
 def rotate_half(x: Tensor) -> Tensor:
@@ -195,7 +195,8 @@ class RotaryMultiheadAttention(nn.Module):
         return self._packs[key]
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Tensor | None = None,
-                key_padding_mask: Tensor | None = None, residual: Tensor | None = None) -> Tensor:
+                key_padding_mask: Tensor | None = None, residual: Tensor | None = None,
+                residual_dropout: float = 0.0) -> Tensor:
         if key is not query or value is not query:
             raise NotImplementedError("the HIP path implements self-attention (query is key is value), "
                                       "which is the only form the model uses (src/transformer.py:347-353)")
@@ -219,7 +220,7 @@ class RotaryMultiheadAttention(nn.Module):
         p_drop = self.dropout.p if self.training else 0.0
         attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin, dropout_p=p_drop,
                                   pre_rotated=rope.applied)
-        return ops.packed_linear(attn, self._pack("out"), residual=residual)
+        return ops.packed_linear(attn, self._pack("out"), residual=residual, residual_dropout=residual_dropout)
 
 
 def _key_valid_bytes(key_padding_mask: Tensor) -> Tensor:
@@ -243,13 +244,13 @@ class TransformerEncoderLayer(nn.Module):
                 src_key_padding_mask: Tensor | None = None) -> Tensor:
         if self.training and self.dropout.p > 0:
             # the two residual dropouts (src/transformer.py:352,361), each fused with its addition
+            # and with the sublayer's last projection: the mask is applied in that GEMM's epilogue
             p = self.dropout.p
             src_norm, src = self.norm1.with_residual(src)
-            attn_output = self.self_attn(src_norm, src_norm, src_norm, attn_mask=src_mask,
-                                         key_padding_mask=src_key_padding_mask)
-            src = ops.dropout_add(attn_output, src, p)
+            src = self.self_attn(src_norm, src_norm, src_norm, attn_mask=src_mask,
+                                 key_padding_mask=src_key_padding_mask, residual=src, residual_dropout=p)
             src_norm, src = self.norm2.with_residual(src)
-            return ops.dropout_add(self.swiglu(src_norm), src, p)
+            return self.swiglu(src_norm, residual=src, residual_dropout=p)
         # residual add fused into the projection epilogue (forward) and into the norm's
         # backward kernel (gradient of the residual stream)
         src_norm, src = self.norm1.with_residual(src)

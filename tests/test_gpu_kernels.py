@@ -452,6 +452,43 @@ def test_dropout_add(dev, dtype, rows, d, p):
     assert float((out.detach()[~keep] - res.detach()[~keep]).abs().max()) == 0.0     # dropped: exactly the residual
 
 
+@pytest.mark.parametrize("M,N,K,p,with_bias", [(512, 768, 768, 0.1, True), (8192, 2304, 256, 0.3, True),
+                                               (1024, 256, 1024, 0.5, False)])
+def test_gemm_dropout_residual(dev, M, N, K, p, with_bias):
+    """ldm_gemm_dropout_residual: R + keep * (A W^T + b) / (1 - p) from one GEMM, with the mask of
+    ldm_dropout_add for the same p and seed (src/transformer.py:352,361 with the projection in front);
+    dropped elements are the residual exactly; shapes it does not take are declined."""
+    from oracle import dropout_oracle as do
+    from src import _native as Nn
+    torch.manual_seed(M + N)
+    seed = 0x0123_4567_0000_0000 + M * 31 + N
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device=dev) if with_bias else None
+    r = torch.randn(M, N, device=dev).bfloat16()
+    c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    lib = Nn.lib()
+    Nn.check(lib.ldm_gemm_dropout_residual(M, N, K, a.data_ptr(), K, w.data_ptr(), K, Nn.ptr(b), r.data_ptr(), N,
+                                           c.data_ptr(), N, p, seed, Nn.stream()), "ldm_gemm_dropout_residual")
+    keep = torch.from_numpy(do.keep_mask_rows(p, seed, M, N)).to(dev)
+    y = a.double() @ w.double().t() + (b.double() if with_bias else 0.0)
+    want = r.double() + torch.where(keep, y * do.scale(p), torch.zeros_like(y))
+    assert rel_err(c.float(), want) < 4e-3
+    assert float((c[~keep].float() - r[~keep].float()).abs().max()) == 0.0
+    # the same mask as the two-call form
+    y16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    Nn.check(lib.ldm_gemm(Nn.BF16, Nn.BF16, 0, 1, M, N, K, 1.0, a.data_ptr(), K, w.data_ptr(), K, y16.data_ptr(), N,
+                          Nn.ptr(b), None, 0, Nn.stream()), "ldm_gemm")
+    two = torch.empty_like(y16)
+    Nn.check(lib.ldm_dropout_add(y16.data_ptr(), r.data_ptr(), two.data_ptr(), M, N, Nn.BF16, p, seed, Nn.stream()), "ldm_dropout_add")
+    assert torch.equal(two == r, c == r) or float(((two == r) != (c == r)).float().mean()) < 1e-4   # (a kept value may round onto the residual)
+    assert rel_err(c.float(), two.float()) < 4e-3
+    # declined: rows not a multiple of 256
+    rc = lib.ldm_gemm_dropout_residual(M - 8, N, K, a.data_ptr(), K, w.data_ptr(), K, Nn.ptr(b), r.data_ptr(), N,
+                                       c.data_ptr(), N, p, seed, Nn.stream())
+    assert rc in (-2, -3)
+
+
 @pytest.mark.parametrize("B,S,H,hd", [(2, 130, 2, 64), (1, 512, 8, 96), (2, 200, 3, 32), (1, 256, 2, 128)])
 def test_attention_bwd_fused_unrope_matches_two_pass(dev, B, S, H, hd):
     """The rotary backward fused into the attention-backward stores gives what the separate

@@ -429,6 +429,47 @@ def test_training_with_dropout(dev, dtype):
     assert e1 == e2 and e1 != l1
 
 
+def test_residual_dropout_in_the_projection_epilogue_equals_the_separate_pass(dev):
+    """The two residual dropouts of the layer (src/transformer.py:352,361) applied in the epilogues of the
+    out- and the down-projection give the step that projection + ldm_dropout_add give: the same masks (the
+    seeds are drawn at the same points), results apart only by the bf16 rounding of the projection output
+    that the fused form skips."""
+    from src import ops
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    V, d, H, L, Fd, B, S = 512, 256, 2, 2, 256, 2, 256
+    torch.manual_seed(3)
+    tr = DiffusionTransformer(DiffusionTransformerConfig(vocab_size=V, d_model=d, nhead=H, num_layers=L, dim_feedforward=Fd,
+                                                         dropout=0.2, layer_norm_eps=1e-12)).to(dev).set_compute_dtype(torch.bfloat16)
+    ids = torch.randint(0, V, (B, S), device=dev)
+    ids[ids == 103] = 104
+    masked = ids.clone()
+    masked[torch.rand(B, S, device=dev) < 0.5] = 103
+    att = torch.ones(B, S, dtype=torch.long, device=dev)
+    tr.train()
+
+    def run(fused):
+        old = ops.FUSED_RESIDUAL_DROPOUT
+        ops.FUSED_RESIDUAL_DROPOUT = fused
+        try:
+            tr.zero_grad(set_to_none=True)
+            torch.manual_seed(11)
+            loss = tr.masked_token_loss(masked, ids, 103, att)
+            loss.backward()
+            return loss.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()}
+        finally:
+            ops.FUSED_RESIDUAL_DROPOUT = old
+
+    lf, gf = run(True)
+    lu, gu = run(False)
+    assert abs(lf - lu) < 2e-3 * abs(lu)
+    flat = lambda g: torch.cat([v.flatten().double() for n, v in sorted(g.items())])
+    assert rel_err(flat(gf), flat(gu)) < 2e-2
+    # and against the residual add without dropout the loss differs
+    tr.eval()
+    with torch.no_grad():
+        assert tr.masked_token_loss(masked, ids, 103, att).item() != lf
+
+
 def test_long_sequence_wide_model_properties(dev):
     """One layer of the ~1B configuration (d=2048, 16 heads of 128, ff=5632, V=32000) at S=4096, the
     largest sequence length of the benchmark configurations, ragged: the trainer-step loss (LM head on
