@@ -10,7 +10,8 @@ runs in the gfx950 library instead of ATen:
 * q/k/v projections  -> ONE packed GEMM (weights stay three parameters) whose epilogue also applies
                         RoPE and q/sqrt(hd) (``ldm_gemm_qkv_rope``; ``ldm_rope_qk`` in place otherwise)
 * scores/softmax/PV  -> ``ldm_attn_fwd/bwd`` (flash attention in bf16)
-* out-proj, w3       -> GEMM with bias + residual epilogue
+* out-proj, w3       -> GEMM with bias + residual epilogue; in training with dropout > 0 the epilogue also
+                        applies the layer's residual dropout (``ldm_gemm_dropout_residual``)
 * w1/w2              -> ONE packed GEMM that also emits ``a * silu(g)`` (``ldm_gemm_swiglu_fwd``)
 
 ``compute_dtype`` selects the arithmetic: ``torch.float32`` (default; every
