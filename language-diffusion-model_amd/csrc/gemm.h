@@ -50,3 +50,9 @@ int ldm_gemm_mfma256_bf16_swiglu_fwd(int64_t T, int64_t F, int64_t K, const void
 int ldm_gemm_mfma256_bf16_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, int64_t S, const void *x, int64_t ldx,
                                    const void *W, int64_t ldw, const float *bias, const float *cos_t, const float *sin_t,
                                    const float *step, float q_scale, void *qkv, int64_t ld_qkv, hipStream_t s);
+
+// four-wave kernel (gemm_mfma4w.hip): A [M, K], B [N, K] K-contiguous, bf16 output, full 256 x 256 tiles,
+// optional bias; LDM_E_SHAPE / LDM_E_ALIGN for anything else
+bool ldm_gemm_4w_enabled();
+int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb,
+                         void *C, int64_t ldc, const float *bias, hipStream_t s);

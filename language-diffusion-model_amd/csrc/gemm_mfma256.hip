@@ -1186,6 +1186,11 @@ double quant_eff(int64_t tiles) { return (double)tiles / (double)(ceil_div(tiles
 int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                           const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
                           const float *bias, const void *R, int64_t ldr, hipStream_t s) {
+  // the four-wave kernel takes what it can (K-contiguous operands, full tiles, no residual)
+  if (ldm_gemm_4w_enabled() && out_dtype == LDM_BF16 && !transA && transB && !R && alpha == 1.0f) {
+    const int rc4 = ldm_gemm_mfma4w_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, s);
+    if (rc4 != LDM_E_SHAPE && rc4 != LDM_E_ALIGN) return rc4;
+  }
   MArgs g;
   const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, R, ldr);
   if (rc) return rc;
