@@ -193,6 +193,13 @@ int ldm_colsum(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float
 /* Elementwise cast fp32 -> bf16 (weight shadows), n elements. */
 int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
 
+/* dst[c, r] = src[r, c] for bf16 (any 2-byte) elements, src [rows, cols] with row stride ld_src, dst
+ * [cols, rows] with row stride ld_dst.  Keeps a K-contiguous copy of each projection weight for the
+ * input-gradient product dx = dy W of nn.Linear's backward (src/transformer.py:208-212,288,91-95 under
+ * autograd): with W^T stored [in, out] that product reads both operands along K, like the forward. */
+int ldm_transpose_bf16(const void *src, int64_t ld_src, void *dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                       void *stream);
+
 /* ---------------------------------------------------------------- attention
  * RotaryMultiheadAttention.forward lines 255-285 (src/transformer.py) after the
  * projections and RoPE: non-causal softmax(q k^T) v per (batch, head) with padded

@@ -1107,6 +1107,36 @@ extern "C" int ldm_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void
   return LDM_OK;
 }
 
+// dst[c, r] = src[r, c] for 2-byte elements: 64 x 64 tiles through LDS (rows padded to 66 elements, so that the
+// column-wise reads of the second half do not all fall into one bank)
+__global__ __launch_bounds__(256) void transpose16_k(const bf16_t *__restrict__ src, int64_t lds_, bf16_t *__restrict__ dst,
+                                                       int64_t ldd, int64_t R, int64_t Cn) {
+  __shared__ bf16_t tile[64][66];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+  for (int i = t; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < Cn) ? src[(r0 + r) * lds_ + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = t; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < Cn && r0 + r < R) dst[(c0 + c) * ldd + r0 + r] = tile[r][c];
+  }
+}
+
+extern "C" int ldm_transpose_bf16(const void *src, int64_t ld_src, void *dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                                  void *stream) {
+  if (rows < 0 || cols < 0) return LDM_E_BADARG;
+  if (rows == 0 || cols == 0) return LDM_OK;
+  if (!src || !dst || ld_src < cols || ld_dst < rows) return LDM_E_BADARG;
+  if (ceil_div(rows, 64) > 65535) return LDM_E_SHAPE;
+  hipLaunchKernelGGL(transpose16_k, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t *)src, ld_src, (bf16_t *)dst, ld_dst, rows, cols);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
 extern "C" int ldm_dropout_add(const void *y, const void *res, void *out, int64_t rows, int64_t d, int dtype, float p,
                                uint64_t seed, void *stream) {
   if (rows < 0 || d <= 0 || !(p >= 0.0f) || !(p < 1.0f)) return LDM_E_BADARG;

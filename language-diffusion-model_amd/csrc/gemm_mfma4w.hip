@@ -413,9 +413,11 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
   g.bias = bias;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn;
   {
-    // m-tiles per band of the tile walk: the band's A panel is sized to about 6 MB (as gemm_mfma256.hip)
+    // m-tiles per band of the tile walk: at most 8, fewer while the band's A panel exceeds 8 MB (measured at
+    // M = 262144, one box: K = 768 -- N = 768: 290 us at 8 against 302 at 16; N = 2304: 829 against 998;
+    // K = 2304, N = 768: 691 at 4 or 8 against 749 at 16)
     static const int env = getenv("LDM_GEMM_BAND") ? atoi(getenv("LDM_GEMM_BAND")) : 0;
-    int b = 16;
+    int b = 8;
     while (b > 2 && (int64_t)b * 512 * K > (int64_t)8 << 20) b >>= 1;
     g.band_m = env > 0 ? env : b;
   }

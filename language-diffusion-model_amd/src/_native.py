@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 15   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 16   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -54,6 +54,7 @@ SIGNATURES = {
     "ldm_colsum_ws_floats": (_i64, [_i64, _i64]),
     "ldm_colsum": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ldm_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "ldm_transpose_bf16": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "ldm_attn_saved_bytes": (_i64, [_i32, _i64, _i64, _i64, _i64]),
     "ldm_attn_bwd_ws_bytes": (_i64, [_i32, _i64, _i64, _i64, _i64]),
     "ldm_attn_fwd": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),

@@ -80,6 +80,21 @@ def parameters_changed() -> None:
     WEIGHTS_EPOCH += 1
 
 
+# Moves whenever the CONTENT of a packed copy may have changed without ``PackedWeights.get`` rebuilding it:
+# FusedAdamW refreshes the copies inside its update kernel.  The transposed copies (``get_t``) follow it.
+SHADOW_GEN = 0
+
+
+def shadows_refreshed() -> None:
+    global SHADOW_GEN
+    SHADOW_GEN += 1
+
+
+# dx = dy @ W with a K-contiguous W^T copy (the same operand layout as the forward, which the four-wave
+# GEMM takes) instead of the strided read of W; LDM_DX_WT=0 keeps the strided form (A/B measurements)
+DX_TRANSPOSED_WEIGHTS = os.environ.get("LDM_DX_WT", "1") != "0"
+
+
 class PackedWeights:
     def __init__(self, weights, biases, dtype: torch.dtype, name: str = "linear"):
         self.name = name
@@ -94,6 +109,9 @@ class PackedWeights:
         self._key = None
         self.w = None
         self.b = None
+        self._gen = 0        # rebuilds of w by get()
+        self.wt = None       # transposed copy (get_t)
+        self._t_key = None
 
     def get(self):
         key = (WEIGHTS_EPOCH,) + tuple((p._version, p.data_ptr()) for p in self.weights + self.biases)
@@ -115,7 +133,25 @@ class PackedWeights:
                 self.b[off:off + n].copy_(bs.detach())
                 off += n
             self._key = key
+            self._gen += 1
         return self.w, self.b
+
+    def get_t(self):
+        """bf16 W^T [k, n_pad] (row stride n_pad) of the packed weights, for the input-gradient product
+        dx[T, k] = dy[T, n_pad] @ W[n_pad, k]: with W^T both operands are read along the reduction, the layout
+        of the forward GEMM.  Rebuilt (one transpose pass over the weights) when the packed copy changed.
+        None for fp32 packs."""
+        w, _ = self.get()
+        if self.dtype != torch.bfloat16:
+            return None
+        key = (SHADOW_GEN, self._gen, w.data_ptr())
+        if key != self._t_key or self.wt is None or self.wt.device != w.device:
+            if self.wt is None or self.wt.device != w.device:
+                self.wt = torch.empty(self.k, self.n_pad, dtype=self.dtype, device=w.device)
+            N.check(N.lib().ldm_transpose_bf16(w.data_ptr(), self.k, self.wt.data_ptr(), self.n_pad, self.n_pad, self.k,
+                                               N.stream()), "ldm_transpose_bf16")
+            self._t_key = key
+        return self.wt
 
 
 class _ZeroPool:
@@ -193,6 +229,17 @@ def _gemm(in_dt, out_dt, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, res
         N.check(N.lib().ldm_gemm(N.dtype_code(in_dt), N.dtype_code(out_dt), ta, tb, m, n, k, alpha,
                                  a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
                                  N.ptr(bias), N.ptr(res), ldr, N.stream()), "ldm_gemm")
+
+
+def _input_grad(pack, dt, T, k, n_pad, g, w):
+    """dx[T, k] = g[T, n_pad] @ W[n_pad, k] (nn.Linear's input gradient)."""
+    dx = torch.empty(T, k, dtype=dt, device=g.device)
+    wt = pack.get_t() if (DX_TRANSPOSED_WEIGHTS and dt == torch.bfloat16 and T >= 256) else None
+    if wt is not None:
+        _gemm(dt, dt, 0, 1, T, k, n_pad, g, n_pad, wt, n_pad, dx, k, tag="gemm.dx")
+    else:
+        _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
+    return dx
 
 
 FUSED_RESIDUAL_DROPOUT = os.environ.get("LDM_FUSED_RES_DROPOUT", "1") != "0"   # residual dropout inside the projection's epilogue
@@ -366,8 +413,7 @@ class _PackedLinear(torch.autograd.Function):
         g = _drop_grad(g, ctx.drop)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(T, k, dtype=dt, device=g.device)
-            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
+            dx = _input_grad(pack, dt, T, k, n_pad, g, w)
         grads_w, grads_b = _weight_bias_grads(pack, g, x2, x2.stride(0), T, k, g.device, dt)
         dres = gy.reshape(ctx.res_shape) if ctx.res_shape is not None else None
         return (dx, dres, None, None, None, None, *grads_w, *grads_b)
@@ -649,8 +695,7 @@ class _SwiGLUUp(torch.autograd.Function):
             g[:, :n].copy_(gy)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(T, k, dtype=dt, device=g.device)
-            _gemm(dt, dt, 0, 0, T, k, n_pad, g, n_pad, w, k, dx, k, tag="gemm.dx")
+            dx = _input_grad(pack, dt, T, k, n_pad, g, w)
         grads_w, grads_b = _weight_bias_grads(pack, g, x2, x2.stride(0), T, k, g.device, dt)
         return (dx, None, *grads_w, *grads_b)
 

@@ -123,4 +123,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                            N.stream()), "ldm_adamw_step")
         for pk in getattr(self, "_stale_packs", ()):
             pk._key = None
+        if self._shadows:
+            from . import ops
+            ops.shadows_refreshed()      # the packed copies changed under their keys: transposed copies follow
         return loss

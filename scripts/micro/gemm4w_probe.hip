@@ -1098,9 +1098,10 @@ __device__ __forceinline__ void g4w5_body(const PArgs &g, char *smem) {
         else wait_vm<8 + (sq >= 0 ? SPS : 0)>();
       }
       const int hpair = cur == 0 ? p + 4 : p + 3;
-      unsigned voff = (cur == 1 ? laneB : laneA) + hpair * 64;
+      constexpr bool opb = (ABL & 2048) ? cur == 0 : cur == 1;
+      unsigned voff = (opb ? laneB : laneA) + hpair * 64;
       unsigned voff2 = voff + 64;
-      unsigned mA = m0_of(hpair, cur == 1), mB = m0_of(hpair + 1, cur == 1);
+      unsigned mA = m0_of(hpair, opb), mB = m0_of(hpair + 1, opb);
       unsigned va = lane_rd + lds_base + ((p + 1) % NSLOT) * HT;
       unsigned soff = (unsigned)(sq >= 0 ? sq / 4 : 0) * ldc16;
       asm volatile("" : "+v"(va), "+v"(voff), "+v"(voff2), "+s"(mA), "+s"(mB), "+s"(soff));
@@ -1120,7 +1121,7 @@ __device__ __forceinline__ void g4w5_body(const PArgs &g, char *smem) {
         constexpr int s_ = decltype(S)::value, gq = s_ % 8, j = s_ / 8;
         constexpr int gst = (2 * WR + 5) % 8;
         if constexpr (gq == 2 * WR || gq == 2 * WR + 1) {
-          if constexpr (do_issue) dma(std::integral_constant<int, j>{}, cur == 1, gq == 2 * WR ? voff : voff2);
+          if constexpr (do_issue) dma(std::integral_constant<int, j>{}, opb, gq == 2 * WR ? voff : voff2);
         } else if constexpr (gq == gst) {
           if constexpr (sq >= 0 && j < SPS) store_q(pk[sq + j], srd_prev, SPS == 4 ? soff : (unsigned)((sq + j) / 4) * ldc16, std::integral_constant<int, (sq + j) % 4>{});
         } else if constexpr (!(ABL & 2)) {
@@ -1406,11 +1407,9 @@ int main(int argc, char **argv) {
     for (int round = 0; round < 2; ++round) {
       if (ldm_gemm)
         run("library 8-wave", [&]() { int rc = ldm_gemm(1, 1, 0, 1, M, N, K, 1.0f, dA, K, dB, K, dC, N, nullptr, nullptr, 0, nullptr); if (rc) { printf("ldm_gemm rc %d\n", rc); exit(1); } }, round == 0);
-      run("v4 direct epilogue", [&]() { launch4<2, 64>(g); }, round == 0);
       run("v5 deferred plain stores, 4/step", [&]() { launch5<4>(g); }, round == 0);
-      run("v5 deferred plain stores, 2/step", [&]() { launch5<2>(g); }, round == 0);
-      run("v5 deferred nt stores, 4/step", [&]() { launch5<4, 1024>(g); }, round == 0);
-      run("v4 noepi", [&]() { launch4<1, 64>(g); }, false);
+      run("v5, A pieces 2 steps ahead, B 3", [&]() { launch5<4, 2048>(g); }, round == 0);
+      run("v5, no DMA in the loop", [&]() { launch5<4, 1>(g); }, false);
     }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dC2)); CK(hipFree(drows)); CK(hipFree(dref));
   }
