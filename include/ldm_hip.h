@@ -83,7 +83,7 @@ int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd, const void
  * loops, harnesses that forbid hipMalloc): the same kernels and results, but the dw partials live in a
  * fixed 8 MiB device array inside the library instead of a caller-provided workspace, so the call
  * needs no buffer beyond its inputs and outputs and allocates nothing.  No counterpart in the
- * reference.  Limits: d <= ldm_rmsnorm_bwd_noalloc_max_d() (8192; larger returns LDM_E_WORKSPACE).
+ * reference.  Limits: d <= ldm_rmsnorm_bwd_noalloc_max_d() (4096; larger returns LDM_E_WORKSPACE).
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
  * threads) race; stream-ordered calls are safe.  With d <= 1024 the result is bit-identical to
  * ldm_rmsnorm_bwd; above that fewer workgroups share the array, so dw is summed in a different
@@ -248,6 +248,17 @@ int ldm_attn_bwd_dropout(int dtype, const void *qkv, int64_t ld_qkv, const uint8
                          const void *do_, int64_t ld_o, const void *saved, void *dqkv, void *ws,
                          const float *cos_t, const float *sin_t, float q_scale, float p, uint64_t seed,
                          void *stream);
+/* The forward with the additive mask of `scores = scores + attn_mask` (src/transformer.py:267-268;
+ * the model itself passes none, :435).  LDM_F32 only (LDM_E_DTYPE otherwise): the path that
+ * materialises the scores.  add_mask: fp32, element (b, h, q, k) at
+ * add_mask[b*mask_sb + h*mask_sh + q*mask_sr + k] -- strides in elements, 0 broadcasts that axis, the
+ * key axis is contiguous -- added before the key mask and the softmax.  p may be 0 (ws then unused).
+ * `saved` holds the resulting probabilities, so ldm_attn_bwd / ldm_attn_bwd_dropout (same p, seed)
+ * are its backward unchanged; no gradient flows to the mask. */
+int ldm_attn_fwd_addmask(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                         const float *add_mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sr,
+                         int64_t batch, int64_t nhead, int64_t seq, int64_t hd, void *o, int64_t ld_o,
+                         void *saved, void *ws, float p, uint64_t seed, void *stream);
 
 /* ---------------------------------------------------------------- residual dropout
  * out = res + keep * y / (1 - p): the `src + self.dropout(...)` of the encoder layer
@@ -365,6 +376,18 @@ typedef struct {
 } ldm_adamw_tensor;
 int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, void *stream);
+/* The same update behind a device-side gate, for the step whose loss had no participating position:
+ * the reference returns a constant there (src/loss.py:18-19), every .grad stays None and
+ * optimizer.step() (src/trainer.py:75,137) changes nothing -- no decay, no moment update, no step
+ * count.  gate: device fp32[1], the count_out of the loss kernels; when *gate == 0 the launch leaves
+ * p, m, v and the shadows as they are.  skipped (nullable): device int32[1], the number of updates
+ * gated off so far; `step` is the host's count including those, and the bias corrections use
+ * step - *skipped.  ldm_adamw_gate_commit adds 1 to *skipped when *gate == 0: call it once after the
+ * last ldm_adamw_step_gated of an optimizer step.  No host synchronisation anywhere. */
+int ldm_adamw_step_gated(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, float grad_scale, const float *gate,
+                         const int32_t *skipped, void *stream);
+int ldm_adamw_gate_commit(const float *gate, int32_t *skipped, void *stream);
 
 /* ---------------------------------------------------------------- batch producer
  * The batch contract of the training step, {"input_ids", "attention_mask"}: int64 [batch, smax] each

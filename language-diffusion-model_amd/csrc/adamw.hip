@@ -25,9 +25,25 @@ struct AdamTensors {
 
 struct AdamScalars {
   float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale;
+  const float *gate;        // nullable: the whole update is skipped when *gate == 0
+  const int32_t *skipped;   // nullable: updates skipped so far (they did not advance the step count)
+  int64_t step;
 };
 
+__global__ void adamw_gate_commit_k(const float *gate, int32_t *skipped) {
+  if (gate[0] == 0.0f) skipped[0] += 1;
+}
+
 __global__ __launch_bounds__(256) void adamw_multi_k(AdamTensors t, AdamScalars s) {
+  if (s.gate && s.gate[0] == 0.0f) return;
+  if (s.skipped) {
+    const int32_t sk = s.skipped[0];
+    if (sk > 0) {   // bias corrections of the step count without the skipped updates
+      const double k = (double)(s.step - sk > 1 ? s.step - sk : 1);
+      s.bc1 = (float)(1.0 - pow((double)s.beta1, k));
+      s.bc2_sqrt = (float)sqrt(1.0 - pow((double)s.beta2, k));
+    }
+  }
   // locate the tensor of this workgroup's chunk (count <= 24: a scan over scalar registers)
   const int64_t chunk = blockIdx.x;
   int ti = 0;
@@ -92,8 +108,9 @@ __global__ __launch_bounds__(256) void adamw_multi_k(AdamTensors t, AdamScalars 
 
 }  // namespace
 
-extern "C" int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, float grad_scale, void *stream) {
+extern "C" int ldm_adamw_step_gated(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                    const float *gate, const int32_t *skipped, void *stream) {
   if (count < 0 || step < 1) return LDM_E_BADARG;
   if (count == 0) return LDM_OK;
   if (!tensors) return LDM_E_BADARG;
@@ -110,6 +127,7 @@ extern "C" int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, in
   s.lr = lr; s.beta1 = beta1; s.beta2 = beta2; s.eps = eps; s.weight_decay = weight_decay; s.grad_scale = grad_scale;
   s.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   s.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  s.gate = gate; s.skipped = skipped; s.step = step;
   hipStream_t st = (hipStream_t)stream;
   int64_t i = 0;
   while (i < count) {
@@ -131,5 +149,18 @@ extern "C" int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, in
     hipLaunchKernelGGL(adamw_multi_k, dim3((unsigned)chunks), dim3(256), 0, st, t, s);
     LDM_CHECK_LAUNCH();
   }
+  return LDM_OK;
+}
+
+extern "C" int ldm_adamw_step(const ldm_adamw_tensor *tensors, int64_t count, int64_t step, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, float grad_scale, void *stream) {
+  return ldm_adamw_step_gated(tensors, count, step, lr, beta1, beta2, eps, weight_decay, grad_scale, nullptr, nullptr,
+                              stream);
+}
+
+extern "C" int ldm_adamw_gate_commit(const float *gate, int32_t *skipped, void *stream) {
+  if (!gate || !skipped) return LDM_E_BADARG;
+  hipLaunchKernelGGL(adamw_gate_commit_k, dim3(1), dim3(1), 0, (hipStream_t)stream, gate, skipped);
+  LDM_CHECK_LAUNCH();
   return LDM_OK;
 }

@@ -4,7 +4,8 @@
 
 int ldm_attn_fwd_f32(const float *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
                      int64_t hd, float *o, int64_t ld_o, float *probs, float *dropped, unsigned drop_thresh,
-                     uint64_t seed, hipStream_t s);
+                     uint64_t seed, hipStream_t s, const float *add_mask, int64_t mask_sb, int64_t mask_sh,
+                     int64_t mask_sr);
 int ldm_attn_bwd_f32(const float *qkv, int64_t ld, int64_t B, int64_t H, int64_t S, int64_t hd, const float *dout,
                      int64_t ld_o, const float *probs, float *dqkv, float *dprobs, unsigned drop_thresh, uint64_t seed,
                      hipStream_t s);

@@ -43,20 +43,34 @@ static int64_t drop_threshold(float p) {
 
 static int attn_fwd_impl(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,
                          int64_t nhead, int64_t seq, int64_t hd, void *o, int64_t ld_o, void *saved, void *ws,
-                         unsigned thresh, uint64_t seed, void *stream) {
+                         unsigned thresh, uint64_t seed, void *stream, const float *add_mask = nullptr,
+                         int64_t mask_sb = 0, int64_t mask_sh = 0, int64_t mask_sr = 0) {
   if (batch < 0 || nhead <= 0 || seq < 0 || hd <= 0) return LDM_E_BADARG;
   if (batch == 0 || seq == 0) return LDM_OK;
   if (!qkv || !o || !saved) return LDM_E_BADARG;
   if (ld_qkv < 3 * nhead * hd || ld_o < nhead * hd) return LDM_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  if (add_mask && dtype != LDM_F32) return LDM_E_DTYPE;
   if (dtype == LDM_BF16)
     return ldm_flash_fwd_bf16((const bf16_t *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (bf16_t *)o, ld_o,
                               (float *)saved, olo_enabled() ? (bf16_t *)((char *)saved + lse_bytes(batch, nhead, seq)) : nullptr,
                               thresh, seed, s);
   if (dtype == LDM_F32)
     return ldm_attn_fwd_f32((const float *)qkv, ld_qkv, key_valid, batch, nhead, seq, hd, (float *)o, ld_o,
-                            (float *)saved, (float *)ws, thresh, seed, s);
+                            (float *)saved, (float *)ws, thresh, seed, s, add_mask, mask_sb, mask_sh, mask_sr);
   return LDM_E_DTYPE;
+}
+
+extern "C" int ldm_attn_fwd_addmask(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid,
+                                    const float *add_mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sr,
+                                    int64_t batch, int64_t nhead, int64_t seq, int64_t hd, void *o, int64_t ld_o,
+                                    void *saved, void *ws, float p, uint64_t seed, void *stream) {
+  const int64_t t = drop_threshold(p);
+  if (t < 0 || !add_mask || mask_sb < 0 || mask_sh < 0 || mask_sr < 0) return LDM_E_BADARG;
+  if (dtype != LDM_F32) return LDM_E_DTYPE;
+  if (t > 0 && !ws) return LDM_E_WORKSPACE;
+  return attn_fwd_impl(dtype, qkv, ld_qkv, key_valid, batch, nhead, seq, hd, o, ld_o, saved, ws, (unsigned)t, seed,
+                       stream, add_mask, mask_sb, mask_sh, mask_sr);
 }
 
 extern "C" int ldm_attn_fwd(int dtype, const void *qkv, int64_t ld_qkv, const uint8_t *key_valid, int64_t batch,

@@ -8,15 +8,27 @@
 
 namespace {
 
+// the additive mask of one launch: element (b, h, q, k) at add[b*sb + h*sh + q*sr + k] (strides in
+// elements; 0 broadcasts), added to the scores before the key mask as src/transformer.py:267-274 does
+struct AddMask {
+  const float *add;
+  int64_t sb, sh, sr, nhead, seq_q;
+};
+
 // one wave per score row, in place
 __global__ __launch_bounds__(256) void softmax_rows_k(float *scores, const uint8_t *key_valid, int64_t rows,
-                                                      int64_t rows_per_batch, int64_t seq_k) {
+                                                      int64_t rows_per_batch, int64_t seq_k, AddMask am) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < rows; r += nwaves) {
     float *row = scores + r * seq_k;
     const uint8_t *kv = key_valid ? key_valid + (r / rows_per_batch) * seq_k : nullptr;
+    if (am.add) {   // row r = ((b * nhead) + h) * seq_q + q
+      const int64_t q = r % am.seq_q, bh = r / am.seq_q;
+      const float *ar = am.add + (bh / am.nhead) * am.sb + (bh % am.nhead) * am.sh + q * am.sr;
+      for (int64_t c = lane; c < seq_k; c += 64) row[c] += ar[c];   // each lane re-reads only its own columns
+    }
     float mx = -INFINITY;
     for (int64_t c = lane; c < seq_k; c += 64) {
       const float v = (kv && !kv[c]) ? -INFINITY : row[c];
@@ -84,16 +96,21 @@ inline unsigned wave_grid(int64_t rows) {
 
 }  // namespace
 
-extern "C" int ldm_softmax_rows_f32(float *scores, const uint8_t *key_valid, int64_t batch, int64_t nhead,
-                                    int64_t seq_q, int64_t seq_k, void *stream) {
+static int softmax_rows_launch(float *scores, const uint8_t *key_valid, int64_t batch, int64_t nhead, int64_t seq_q,
+                               int64_t seq_k, AddMask am, void *stream) {
   if (batch < 0 || nhead < 0 || seq_q < 0 || seq_k < 0) return LDM_E_BADARG;
   const int64_t rows = batch * nhead * seq_q;
   if (rows == 0 || seq_k == 0) return LDM_OK;
   if (!scores) return LDM_E_BADARG;
   hipLaunchKernelGGL(softmax_rows_k, dim3(wave_grid(rows)), dim3(256), 0, (hipStream_t)stream, scores, key_valid,
-                     rows, nhead * seq_q, seq_k);
+                     rows, nhead * seq_q, seq_k, am);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
+}
+
+extern "C" int ldm_softmax_rows_f32(float *scores, const uint8_t *key_valid, int64_t batch, int64_t nhead,
+                                    int64_t seq_q, int64_t seq_k, void *stream) {
+  return softmax_rows_launch(scores, key_valid, batch, nhead, seq_q, seq_k, AddMask{nullptr, 0, 0, 0, 1, 1}, stream);
 }
 
 extern "C" int ldm_softmax_bwd_rows_f32(const float *probs, float *dprobs_inout, int64_t rows, int64_t cols,
@@ -109,7 +126,8 @@ extern "C" int ldm_softmax_bwd_rows_f32(const float *probs, float *dprobs_inout,
 
 int ldm_attn_fwd_f32(const float *qkv, int64_t ld, const uint8_t *key_valid, int64_t B, int64_t H, int64_t S,
                      int64_t hd, float *o, int64_t ld_o, float *probs, float *dropped, unsigned drop_thresh,
-                     uint64_t seed, hipStream_t s) {
+                     uint64_t seed, hipStream_t s, const float *add_mask, int64_t mask_sb, int64_t mask_sh,
+                     int64_t mask_sr) {
   if (drop_thresh && !dropped) return LDM_E_WORKSPACE;
   const int64_t D = H * hd;
   const ldm_bstride s_qkv{S * ld, hd}, s_p{H * S * S, S * S}, s_o{S * ld_o, hd};
@@ -117,7 +135,7 @@ int ldm_attn_fwd_f32(const float *qkv, int64_t ld, const uint8_t *key_valid, int
   int rc = ldm_gemm_generic(LDM_F32, LDM_F32, 0, 1, S, S, hd, 1.0f, qkv, ld, s_qkv, qkv + D, ld, s_qkv, probs, S,
                             s_p, nullptr, nullptr, 0, B * H, H, s);
   if (rc) return rc;
-  rc = ldm_softmax_rows_f32(probs, key_valid, B, H, S, S, s);
+  rc = softmax_rows_launch(probs, key_valid, B, H, S, S, AddMask{add_mask, mask_sb, mask_sh, mask_sr, H, S}, s);
   if (rc) return rc;
   const float *pv = probs;
   if (drop_thresh) {   // the saved probabilities stay undropped (the softmax Jacobian needs them)

@@ -1806,7 +1806,10 @@ int ldm_flash_bwd_bf16(const bf16_t *qkv, int64_t ld, const uint8_t *key_valid, 
   int rc = check(a);
   if (rc) return rc;
   if (!aligned_to(qkv, 16) || !aligned_to(dout, 16) || !aligned_to(o, 8) || !aligned_to(dqkv, 8)) return LDM_E_ALIGN;
-  if (attn_dma_enabled() && a.ld % 8 == 0 && a.ld_o % 8 == 0 && aligned_to(a.qkv, 16) && aligned_to(a.dout, 16)) {
+  // (the LDS-DMA kernels fetch q/k/v, dO, O and the stored rounding residual of O in 16-byte pieces: an O or a
+  // residual that is only 8-byte aligned goes to the register-staged kernels)
+  if (attn_dma_enabled() && a.ld % 8 == 0 && a.ld_o % 8 == 0 && aligned_to(a.qkv, 16) && aligned_to(a.dout, 16) &&
+      aligned_to(a.o_in, 16) && (!a.o_lo_in || aligned_to(a.o_lo_in, 16))) {
     if (hd == 96) return flash2_bwd_launch<96>(a, s);
     if (hd == 128) return flash2_bwd_launch<128>(a, s);
   }

@@ -871,7 +871,9 @@ extern "C" int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd,
   hipStream_t s = (hipStream_t)stream;
   if (T == 0) return (int)hipMemsetAsync(dw, 0, d * sizeof(float), s);
   if (!x || !w || !rstd || !dy || !dx || !dw_partial) return LDM_E_BADARG;
-  if (d % 4 || d > 8192) return LDM_E_SHAPE;
+  // (the kernels keep four rows of d floats in LDS: 64 KiB, the limit of a launch without a raised
+  // dynamic-LDS attribute, at d = 4096)
+  if (d % 4 || d > 4096) return LDM_E_SHAPE;
   if (!aligned_to(x, 16) || !aligned_to(dy, 16) || !aligned_to(dx, 16) || !aligned_to(w, 16) ||
       (dres && !aligned_to(dres, 16)))
     return LDM_E_ALIGN;
@@ -909,7 +911,7 @@ static int scratch_address(float **out) {
   return LDM_OK;
 }
 
-extern "C" int64_t ldm_rmsnorm_bwd_noalloc_max_d(void) { return 8192; }
+extern "C" int64_t ldm_rmsnorm_bwd_noalloc_max_d(void) { return 4096; }
 
 extern "C" int ldm_rmsnorm_bwd_noalloc(const void *x, const float *w, const float *rstd, const void *dy,
                                        const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,

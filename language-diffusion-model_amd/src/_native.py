@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 16   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 17   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -67,6 +67,8 @@ SIGNATURES = {
     "ldm_dropout_add": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _f32, _u64, _vp]),
     "ldm_gemm_dropout_residual": (_i32, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _f32, _u64, _vp]),
     "ldm_attn_fwd_dropout": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _f32, _u64, _vp]),
+    "ldm_attn_fwd_addmask": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
+                                    _vp, _f32, _u64, _vp]),
     "ldm_attn_bwd_dropout": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _f32, _f32, _u64, _vp]),
     "ldm_ce_fwd": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
@@ -82,6 +84,9 @@ SIGNATURES = {
     "ldm_ce_fwd_grad": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldm_scale_rows_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ldm_adamw_step": (_i32, [C.POINTER(AdamWTensor), _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "ldm_adamw_step_gated": (_i32, [C.POINTER(AdamWTensor), _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp,
+                                    _vp]),
+    "ldm_adamw_gate_commit": (_i32, [_vp, _vp, _vp]),
     "ldm_collate_pad": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ldm_synth_tokens": (_i32, [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _u64, _u64, _vp, _vp, _vp]),
     "ldm_gemm_swiglu_bwd": (_i32, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

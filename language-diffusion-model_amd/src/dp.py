@@ -248,6 +248,11 @@ class HipAccelerator:
                 for m in o.modules():
                     if hasattr(m, "set_compute_dtype"):
                         m.set_compute_dtype(dtype)
+                    # accelerate wraps a prepared model's forward in convert_outputs_to_fp32 under mixed
+                    # precision: the callers of the reference (src/trainer.py:68-69, the sampling loop)
+                    # see fp32 logits.  The fused training loss never forms them, so it is unaffected.
+                    if self.mixed_precision == "bf16" and hasattr(m, "fp32_logits"):
+                        m.fp32_logits = True
                 if self.num_processes > 1 or (dist.is_initialized() and os.environ.get("LDM_DP_FORCE") == "1"):
                     o = GradBucketDataParallel(o, bucket_bytes=self.bucket_bytes, wire_dtype=self.grad_wire_dtype)
                 self._last_model = o

@@ -4,7 +4,9 @@ Same functions and signatures as the reference's ``src/loss.py``
 (``masked_cross_entropy_loss`` :8-28, ``variational_lower_bound_loss`` :31-65).
 Only the participating rows of ``logits`` are read; the "no row participates"
 case is decided on the device (no host synchronisation) and yields 0 with zero
-gradients.
+gradients.  The reference returns a constant there (:18-19), so its optimizer
+step changes nothing; the trainer gets the same effect by handing the loss's row
+count (``ops.LAST_LOSS_COUNT``) to ``FusedAdamW.gate`` when it runs as one process.
 """
 
 from __future__ import annotations

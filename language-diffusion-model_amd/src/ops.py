@@ -841,7 +841,7 @@ class _RopeAttention(torch.autograd.Function):
     mask the kernels regenerate from ``seed`` and the element coordinates; nothing is stored."""
 
     @staticmethod
-    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin, dropout_p=0.0, seed=0, pre_rotated=False):
+    def forward(ctx, qkv, key_valid, B, S, H, hd, cos, sin, dropout_p=0.0, seed=0, pre_rotated=False, add_mask=None):
         N.require_device(qkv)
         lib = N.lib()
         dt = qkv.dtype
@@ -860,13 +860,23 @@ class _RopeAttention(torch.autograd.Function):
                                         1.0 / math.sqrt(hd), 0, N.stream()), "ldm_rope_qk")
         o = torch.empty(B * S, D, dtype=dt, device=qkv.device)
         saved = torch.empty(lib.ldm_attn_saved_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
-        if dropout_p > 0.0:
+        if add_mask is not None:
+            # scores + attn_mask (src/transformer.py:267-268): on the path that materialises the scores
+            ws = (torch.empty(lib.ldm_attn_bwd_ws_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
+                  if dropout_p > 0.0 else None)
+            sb, sh, sr, _ = add_mask.stride()
+            with _Timed("attn.fwd", 4.0 * B * H * S * S * hd):
+                N.check(lib.ldm_attn_fwd_addmask(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), add_mask.data_ptr(), sb, sh,
+                                                 sr, B, H, S, hd, o.data_ptr(), D, saved.data_ptr(), N.ptr(ws),
+                                                 float(dropout_p), int(seed), N.stream()), "ldm_attn_fwd_addmask")
+        elif dropout_p > 0.0:
             # the fp32 path materialises the probabilities: it needs room for their dropped copy
             ws = (torch.empty(lib.ldm_attn_bwd_ws_bytes(code, B, H, S, hd), dtype=torch.uint8, device=qkv.device)
                   if dt == torch.float32 else None)
-            N.check(lib.ldm_attn_fwd_dropout(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
-                                             saved.data_ptr(), N.ptr(ws), float(dropout_p), int(seed), N.stream()),
-                    "ldm_attn_fwd_dropout")
+            with _Timed("attn.fwd", 4.0 * B * H * S * S * hd):
+                N.check(lib.ldm_attn_fwd_dropout(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
+                                                 saved.data_ptr(), N.ptr(ws), float(dropout_p), int(seed), N.stream()),
+                        "ldm_attn_fwd_dropout")
         else:
             with _Timed("attn.fwd", 4.0 * B * H * S * S * hd):
                 N.check(lib.ldm_attn_fwd(code, q2.data_ptr(), 3 * D, N.ptr(key_valid), B, H, S, hd, o.data_ptr(), D,
@@ -894,14 +904,15 @@ class _RopeAttention(torch.autograd.Function):
         p_drop, seed = ctx.dropout
         if p_drop > 0.0:
             fused = FUSED_UNROPE and dt == torch.bfloat16 and hd in (32, 64, 96, 128)
-            N.check(lib.ldm_attn_bwd_dropout(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
-                                             g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
-                                             cos.data_ptr() if fused else None, sin.data_ptr() if fused else None,
-                                             1.0 / math.sqrt(hd), p_drop, seed, N.stream()), "ldm_attn_bwd_dropout")
+            with _Timed("attn.bwd", 10.0 * B * H * S * S * hd):
+                N.check(lib.ldm_attn_bwd_dropout(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                                 g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
+                                                 cos.data_ptr() if fused else None, sin.data_ptr() if fused else None,
+                                                 1.0 / math.sqrt(hd), p_drop, seed, N.stream()), "ldm_attn_bwd_dropout")
             if not fused:
                 N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
                                         1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
-            return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None, None
+            return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None, None, None
         # attention backward with the rotary backward fused into its stores where the kernel has it
         rc = -3
         if FUSED_UNROPE and dt == torch.bfloat16:
@@ -912,27 +923,49 @@ class _RopeAttention(torch.autograd.Function):
             if rc not in (-2, -3):
                 N.check(rc, "ldm_attn_bwd_unrope")
         if rc in (-2, -3):
-            N.check(lib.ldm_attn_bwd(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
-                                     g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), N.stream()),
-                    "ldm_attn_bwd")
+            with _Timed("attn.bwd", 10.0 * B * H * S * S * hd):
+                N.check(lib.ldm_attn_bwd(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
+                                         g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), N.stream()),
+                        "ldm_attn_bwd")
             N.check(lib.ldm_rope_qk(dqkv.data_ptr(), code, B, S, H, hd, 3 * D, cos.data_ptr(), sin.data_ptr(),
                                     1.0 / math.sqrt(hd), 1, N.stream()), "ldm_rope_qk(inverse)")
-        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None, None
+        return dqkv.view(B, S, 3 * D), None, None, None, None, None, None, None, None, None, None, None
 
 
 def rope_attention(qkv: Tensor, key_valid: Tensor | None, B: int, S: int, H: int, hd: int, cos: Tensor,
-                   sin: Tensor, dropout_p: float = 0.0, seed: int | None = None, pre_rotated: bool = False) -> Tensor:
+                   sin: Tensor, dropout_p: float = 0.0, seed: int | None = None, pre_rotated: bool = False,
+                   attn_mask: Tensor | None = None) -> Tensor:
     """``dropout_p`` > 0: attention-probability dropout; ``seed`` (63 bits) defaults to a draw from
     torch's CPU generator, so ``torch.manual_seed`` reproduces the masks.  ``pre_rotated``: q and k in
     ``qkv`` already carry the rotary embedding and the query scale (the projection applied them); the
-    gradient handed back is still the one w.r.t. the un-rotated projection output."""
+    gradient handed back is still the one w.r.t. the un-rotated projection output.
+
+    ``attn_mask``: anything that broadcasts against the scores [B, H, S, S], added to them before the
+    key mask and the softmax (src/transformer.py:267-268).  Served by the fp32 kernels that
+    materialise the scores -- a bf16 ``qkv`` is up-cast for the attention core and the result cast
+    back -- so it costs O(S^2) memory; the model never passes one.  No gradient reaches the mask."""
     if dropout_p > 0.0 and seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin, float(dropout_p), int(seed or 0),
-                                bool(pre_rotated))
+    if attn_mask is None:
+        return _RopeAttention.apply(qkv, key_valid, B, S, H, hd, cos, sin, float(dropout_p), int(seed or 0),
+                                    bool(pre_rotated))
+    if attn_mask.requires_grad:
+        raise NotImplementedError("a gradient with respect to attn_mask is not implemented")
+    m = attn_mask.detach().to(device=qkv.device, dtype=torch.float32)
+    m = torch.broadcast_to(m, (B, H, S, S))
+    if m.stride(3) != 1:
+        m = m.contiguous()
+    out = _RopeAttention.apply(qkv.float(), key_valid, B, S, H, hd, cos, sin, float(dropout_p), int(seed or 0),
+                               bool(pre_rotated), m)
+    return out.to(qkv.dtype)
 
 
 # ----------------------------------------------------------------------------
+# fp32[1] on the device: the number of positions the most recent masked-CE forward averaged over.
+# The trainer hands it to FusedAdamW.gate() so that a step whose loss had no position changes nothing.
+LAST_LOSS_COUNT = None
+
+
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, masked_ids, mask_token_id, mask_bool, att_valid, seq_weight, norm_mode, link):
@@ -972,6 +1005,8 @@ class _MaskedCE(torch.autograd.Function):
             ctx.compact = (rows, cnt)
         ctx.save_for_backward(l2, tg, lse, out)
         ctx.aux = (mi, mb, av, sw, int(mask_token_id), norm_mode, seq, ld, logits.shape, logits.dtype)
+        global LAST_LOSS_COUNT
+        LAST_LOSS_COUNT = out[1:2]
         return out[0].clone()
 
     @staticmethod
@@ -1088,6 +1123,8 @@ class _HeadMaskedCE(torch.autograd.Function):
         ctx.dims = (T, k)
         ctx.done = False
         FUSED_HEAD_STATS["used"] += 1
+        global LAST_LOSS_COUNT
+        LAST_LOSS_COUNT = out[1:2]
         return out[0].clone()
 
     @staticmethod

@@ -30,6 +30,38 @@ class FusedAdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0        # multiplies every gradient inside the update
         self._shadows: dict = {}     # id(param) -> (tensor slice, kind)
         self._shadow_sig = None
+        self._gate = None            # device fp32[1]: the next step() changes nothing when it holds 0
+        self._skipped = None         # device int32[1]: steps gated off since the last reconcile
+
+    # ------------------------------------------------------------------ empty-loss gate
+    def gate(self, count: torch.Tensor | None) -> None:
+        """Make the next ``step()`` a no-op when ``count`` (device fp32[1], the number of positions
+        the loss averaged over) is 0 -- what the reference's step does when the loss had no masked
+        position: src/loss.py:18-19 returns a constant, every ``.grad`` stays None, and
+        torch.optim.AdamW skips such parameters (no weight decay, no moment decay, no step count).
+        Decided on the device; the host never waits.  ``None`` removes the gate."""
+        self._gate = count
+        if count is not None and self._skipped is None:
+            self._skipped = torch.zeros(1, dtype=torch.int32, device=count.device)
+
+    def _reconcile(self) -> None:
+        """Take the gated-off steps out of the per-parameter step counts (reads one int32 back)."""
+        if self._skipped is None:
+            return
+        sk = int(self._skipped.item())
+        if sk:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] -= min(float(sk), float(st["step"]))
+            self._skipped.zero_()
+
+    def state_dict(self):
+        self._reconcile()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._reconcile()
+        return super().load_state_dict(state_dict)
 
     # ------------------------------------------------------------------ weight shadows
     def attach(self, module: torch.nn.Module) -> "FusedAdamW":
@@ -77,6 +109,9 @@ class FusedAdamW(torch.optim.Optimizer):
             from . import ops
             ops.parameters_changed()     # nobody keeps the packed weight copies current: re-cast lazily
         lib = N.lib()
+        gate, self._gate = self._gate, None          # a gate holds for one step
+        gate_ptr = gate.data_ptr() if gate is not None else None
+        skipped_ptr = self._skipped.data_ptr() if self._skipped is not None else None
         for group in self.param_groups:
             entries = []
             step_no = None
@@ -118,9 +153,12 @@ class FusedAdamW(torch.optim.Optimizer):
                         arr[i].shadow, arr[i].shadow_kind = None, 0
                     keep.append(g)
                 b1, b2 = group["betas"]
-                N.check(lib.ldm_adamw_step(arr, len(es), step_no, float(group["lr"]), float(b1), float(b2),
-                                           float(group["eps"]), float(group["weight_decay"]), float(self.grad_scale),
-                                           N.stream()), "ldm_adamw_step")
+                N.check(lib.ldm_adamw_step_gated(arr, len(es), step_no, float(group["lr"]), float(b1), float(b2),
+                                                 float(group["eps"]), float(group["weight_decay"]),
+                                                 float(self.grad_scale), gate_ptr, skipped_ptr, N.stream()),
+                        "ldm_adamw_step_gated")
+        if gate is not None:
+            N.check(lib.ldm_adamw_gate_commit(gate_ptr, skipped_ptr, N.stream()), "ldm_adamw_gate_commit")
         for pk in getattr(self, "_stale_packs", ()):
             pk._key = None
         if self._shadows:

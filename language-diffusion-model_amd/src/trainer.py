@@ -41,6 +41,12 @@ class DiffusionLanguageModelTrainer:
         from .optim import FusedAdamW
         inner = getattr(optimizer, "optimizer", optimizer)    # accelerate keeps the real one here
         self._marks_stale = not (isinstance(inner, FusedAdamW) and getattr(inner, "_module", None) is not None)
+        # One process: a step whose loss had no masked position must change nothing, as in the reference
+        # (src/loss.py:18-19 returns a constant, so optimizer.step() at src/trainer.py:75 sees no gradient).
+        # FusedAdamW decides that on the device.  With several processes the all-reduce averages that
+        # rank's zeros with the other ranks' gradients and every rank steps, which is what DDP does.
+        self._gated = inner if (isinstance(inner, FusedAdamW)
+                                and int(getattr(accelerator, "num_processes", 1)) == 1) else None
 
     def _step(self, batch) -> torch.Tensor:
         input_ids = batch["input_ids"]
@@ -61,6 +67,8 @@ class DiffusionLanguageModelTrainer:
                                                 mask_token_id=self.model.tokenizer.mask_token_id)
         self._stage_loss(loss)
         self.accelerator.backward(loss)
+        if self._gated is not None and loss.is_cuda:
+            self._gated.gate(ops.LAST_LOSS_COUNT)
         self.optimizer.step()
         if self._marks_stale:
             ops.parameters_changed()

@@ -201,9 +201,6 @@ class RotaryMultiheadAttention(nn.Module):
         if key is not query or value is not query:
             raise NotImplementedError("the HIP path implements self-attention (query is key is value), "
                                       "which is the only form the model uses (src/transformer.py:347-353)")
-        if attn_mask is not None:
-            raise NotImplementedError("additive attn_mask is never supplied by the model "
-                                      "(src/transformer.py:435) and is not implemented in the HIP path")
         bsz, seq, _ = query.shape
         cos, sin = self.rotary_emb.half_tables(query, seq)
         key_valid = None
@@ -219,8 +216,9 @@ class RotaryMultiheadAttention(nn.Module):
         qkv = ops.packed_linear(query, self._pack("qkv"), rope=rope)
         # dropout on the attention probabilities (src/transformer.py:278) happens inside the kernels
         p_drop = self.dropout.p if self.training else 0.0
+        # attn_mask (src/transformer.py:267-268; the model passes none, :435) goes to the fp32 kernels
         attn = ops.rope_attention(qkv, key_valid, bsz, seq, self.nhead, self.head_dim, cos, sin, dropout_p=p_drop,
-                                  pre_rotated=rope.applied)
+                                  pre_rotated=rope.applied, attn_mask=attn_mask)
         return ops.packed_linear(attn, self._pack("out"), residual=residual, residual_dropout=residual_dropout)
 
 
@@ -327,8 +325,11 @@ class DiffusionTransformer(nn.Module):
                     kpm = attention_mask == 0
                     kpm._ldm_key_valid = key_valid
                 return layer(x_in, src_key_padding_mask=kpm)
+            # preserve_rng_state: every dropout seed of a layer (attention probabilities, the two residual
+            # dropouts) is drawn from torch's CPU generator inside ``run``; the re-run in backward regenerates
+            # the SAME masks only because checkpoint restores the generator state it recorded in forward
             for layer in self.layers:
-                x = checkpoint(run, layer, x, use_reentrant=False)
+                x = checkpoint(run, layer, x, use_reentrant=False, preserve_rng_state=True)
             return self.norm(x)
         for layer in self.layers:
             x = layer(x, src_key_padding_mask=key_padding_mask)

@@ -321,6 +321,41 @@ def test_recompute_layers_gives_the_same_step(dev, mode):
         assert rel_err(out[True][1][n], g) < (1e-6 if mode == "fp32" else 5e-3), n
 
 
+def test_recompute_layers_with_dropout_regenerates_the_same_masks(dev):
+    """Activation recompute with the YAML's dropout 0.1 (configs/default.yaml:13): the re-run of a layer in
+    backward draws its dropout seeds again from torch's CPU generator, whose state the checkpoint restores, so
+    the masks -- and with them loss and gradients -- are those of the plain run under the same torch seed."""
+    from oracle import step_oracle as so
+    ocfg = so.OracleConfig(vocab_size=30522, d_model=768, nhead=8, num_layers=3, dim_feedforward=1024)
+    params = so.init_params(ocfg, seed=21)
+    B, S = 2, 512
+    ids, att = so.synthetic_batch(B, S, 30522, seed=22, ragged=True, dirty=True)
+    draw = torch.rand(B, S, generator=torch.Generator().manual_seed(23)).to(dev)
+    model = _model_from(params, ocfg, dev, torch.bfloat16, 512)
+    for m in model.transformer.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.1
+    model.masking_strategy = _InjectedDraw(model.masking_strategy, draw)
+    out = {}
+    for rc in (False, True):
+        model.transformer.recompute_layers = rc
+        model.transformer.zero_grad(set_to_none=True)
+        torch.manual_seed(77)
+        loss = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([0.5]))
+        loss.backward()
+        out[rc] = (loss.item(), {n: p.grad.detach().clone() for n, p in model.transformer.named_parameters()})
+    assert out[True][0] == out[False][0]
+    for n, g in out[False][1].items():
+        if n.endswith("k_proj.bias"):
+            continue
+        assert rel_err(out[True][1][n], g) < 5e-3, n
+    # and a different seed gives different masks (the comparison above is not vacuous)
+    model.transformer.zero_grad(set_to_none=True)
+    torch.manual_seed(78)
+    loss2 = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([0.5]))
+    assert loss2.item() != out[True][0]
+
+
 def test_8b_layer_shape_two_layers(dev):
     """The LLaDA-8B layer shape (d=4096, 32 heads of 128, ff=12288, V=126464) at two layers on one GPU:
     against the fp32 oracle at S=1024 (loss and whole gradient 2e-2 in bf16), and at S=4096 the

@@ -302,9 +302,10 @@ def test_colsum(dev):
 
 
 # ------------------------------------------------------------------ attention
-def _attn_ref(qkv, key_valid, B, S, H, hd, keep=None, keep_scale=1.0):
+def _attn_ref(qkv, key_valid, B, S, H, hd, keep=None, keep_scale=1.0, add=None):
     """Reference arithmetic of src/transformer.py:246-285 in fp64 (RoPE + scale included); ``keep``
-    [B,H,S,S] bool with ``keep_scale`` = 1/(1-p) is the dropout of line 278 with a given mask."""
+    [B,H,S,S] bool with ``keep_scale`` = 1/(1-p) is the dropout of line 278 with a given mask; ``add``
+    is the attn_mask of lines 267-268."""
     from oracle import step_oracle as so
     D = H * hd
     x = qkv.double().view(B, S, 3, H, hd)
@@ -316,6 +317,8 @@ def _attn_ref(qkv, key_valid, B, S, H, hd, keep=None, keep_scale=1.0):
     k = k * cos + so._rot_half(k) * sin
     q, k, v = (t.transpose(1, 2) for t in (q, k, v))
     s = (q / math.sqrt(hd)) @ k.transpose(-2, -1)
+    if add is not None:
+        s = s + add.double()
     if key_valid is not None:
         s = s.masked_fill(~key_valid.bool()[:, None, None, :], float("-inf"))
     pr = torch.softmax(s, -1)
@@ -353,6 +356,60 @@ def test_attention_fwd_bwd(dev, dtype, B, S, H, hd, ragged):
     gq, gr = qkv.grad.float().view(B, S, 3, D), qr.grad.view(B, S, 3, D)
     for i, nm in enumerate("qkv"):
         assert rel_err(gq[:, :, i], gr[:, :, i]) < tol, f"d{nm}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", ["SS", "B1SS", "BHSS", "1H1S"])
+def test_attention_additive_mask(dev, dtype, shape):
+    """scores + attn_mask (src/transformer.py:267-268) in every broadcast form, with the key mask on
+    top, forward and backward; a causal -inf part and a finite bias part."""
+    from src import ops
+    from src.transformer import RotaryPositionEmbedding
+    torch.manual_seed(2)
+    B, S, H, hd = 2, 70, 3, 32
+    D = H * hd
+    qkv = (torch.randn(B, S, 3 * D, device=dev) * 1.5).to(dtype).requires_grad_(True)
+    lens = torch.tensor([S, S - 9])
+    key_valid = (torch.arange(S)[None, :] < lens[:, None]).to(torch.uint8).to(dev)
+    causal = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    full = {"SS": (S, S), "B1SS": (B, 1, S, S), "BHSS": (B, H, S, S), "1H1S": (1, H, 1, S)}[shape]
+    m = torch.randn(*full, device=dev)
+    if shape != "1H1S":
+        m = m + causal
+    cos, sin = RotaryPositionEmbedding(hd).half_tables(qkv, S)
+    go = torch.randn(B, S, D, device=dev).to(dtype)
+    o = ops.rope_attention(qkv * 1.0, key_valid, B, S, H, hd, cos, sin, attn_mask=m)
+    assert o.dtype == dtype
+    o.backward(go)
+    qr = qkv.detach().clone().requires_grad_(True)
+    orf = _attn_ref(qr, key_valid, B, S, H, hd, add=m)
+    orf.backward(go.double())
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    assert rel_err(o, orf) < tol, "forward"
+    assert rel_err(qkv.grad.float(), qr.grad) < tol, "dqkv"
+    with pytest.raises(NotImplementedError):
+        ops.rope_attention(qkv * 1.0, key_valid, B, S, H, hd, cos, sin, attn_mask=m.clone().requires_grad_(True))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_module_causal_mask_hides_later_tokens(dev, dtype):
+    """RotaryMultiheadAttention(x, x, x, attn_mask=causal): changing the last token leaves every
+    earlier output row as it was (dropout on the probabilities active)."""
+    from src.transformer import RotaryMultiheadAttention
+    torch.manual_seed(4)
+    B, S, d = 2, 96, 128
+    att = RotaryMultiheadAttention(d, 2, dropout=0.1).to(dev)
+    att.compute_dtype = dtype
+    att.train()
+    x = torch.randn(B, S, d, device=dev).to(dtype)
+    x2 = x.clone()
+    x2[:, -1] += 1.0
+    causal = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    torch.manual_seed(9)
+    y = att(x, x, x, attn_mask=causal)
+    torch.manual_seed(9)
+    y2 = att(x2, x2, x2, attn_mask=causal)
+    assert torch.equal(y[:, :-1], y2[:, :-1]) and not torch.equal(y[:, -1], y2[:, -1])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -542,3 +542,66 @@ def test_fp32_logits_switch_is_an_upcast_of_the_bf16_logits(dev):
     assert abs(loss32.item() - loss16.item()) < 1e-3 * abs(loss16.item())
     for n, p in tr.named_parameters():
         assert rel_err(p.grad, g16[n]) < 2e-2, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_step_without_masked_positions_changes_nothing(dev, dtype):
+    """One process: a batch in which nothing can be masked (special tokens only) gives loss 0, and
+    the optimizer step after it leaves parameters, moments, weight copies and the step count as they
+    were -- the reference's loss is a constant there (src/loss.py:18-19), so its optimizer sees no
+    gradient.  A third, ordinary step then equals the second step of a run that never saw the
+    empty batch (bias corrections of step 2, not 3)."""
+    import random
+
+    from src.dp import HipAccelerator
+    from src.optim import FusedAdamW
+    from src.trainer import DiffusionLanguageModelTrainer
+    g = load_golden("step_hd96.npz")
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    att = torch.from_numpy(g["attention_mask"]).to(dev)
+    empty = torch.zeros_like(ids)
+    empty[:, 0], empty[:, 1] = 101, 102
+    runs = []
+    for with_empty in (True, False):
+        model = _build(g, dev, dtype)
+        acc = HipAccelerator(mixed_precision="bf16" if dtype == torch.bfloat16 else "no", device=dev)
+        model = acc.prepare(model)
+        opt = acc.prepare(FusedAdamW(model.parameters(), lr=5e-4, weight_decay=0.1))
+        trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+        random.seed(1); torch.manual_seed(1)
+        trainer._step({"input_ids": ids, "attention_mask": att})
+        if with_empty:
+            snap = {n: p.detach().clone() for n, p in model.named_parameters()}
+            moments = [(st["exp_avg"].clone(), st["exp_avg_sq"].clone()) for st in opt.state.values()]
+            packs = [pk for m in model.modules() for pk in getattr(m, "_packs", {}).values()]
+            copies = [(pk.w.clone(), pk.b.clone()) for pk in packs]
+            loss = trainer._step({"input_ids": empty, "attention_mask": torch.ones_like(att)})
+            assert trainer.loss_value(loss) == 0.0
+            for n, p in model.named_parameters():
+                assert torch.equal(p.detach(), snap[n]), n
+            for st, (m1, v1) in zip(opt.state.values(), moments):
+                assert torch.equal(st["exp_avg"], m1) and torch.equal(st["exp_avg_sq"], v1)
+            for pk, (w1, b1) in zip(packs, copies):
+                assert torch.equal(pk.w, w1) and torch.equal(pk.b, b1)
+        random.seed(2); torch.manual_seed(2)
+        trainer._step({"input_ids": ids, "attention_mask": att})
+        steps = {float(st["step"]) for st in opt.state_dict()["state"].values()}
+        assert steps == {2.0}, steps
+        runs.append({n: p.detach().clone() for n, p in model.named_parameters()})
+    for n in runs[0]:
+        assert rel_err(runs[0][n], runs[1][n]) < (1e-6 if dtype == torch.float32 else 2e-4), n
+
+
+@pytest.mark.gpu
+def test_prepared_bf16_model_returns_fp32_logits(dev):
+    """accelerate converts a prepared model's outputs to fp32 under mixed precision, so the reference's
+    callers (src/trainer.py:68-69) see fp32 logits: HipAccelerator(mixed_precision="bf16").prepare does the same."""
+    from src.dp import HipAccelerator
+    g = load_golden("step_hd96.npz")
+    ids = torch.from_numpy(g["input_ids"]).to(dev)
+    for mp, want in (("bf16", torch.float32), ("no", torch.float32)):
+        model = HipAccelerator(mixed_precision=mp, device=dev).prepare(_build(g, dev, torch.float32))
+        logits, _, _ = model(input_ids=ids)
+        assert logits.dtype == want, mp
+        assert model.transformer.compute_dtype == (torch.bfloat16 if mp == "bf16" else torch.float32)

@@ -57,12 +57,20 @@ def test_step_golden(name):
         assert rel_err(loss, g[f"loss_{mode}"]) < ltol
         if mode == "fp32":
             assert rel_err(logits, g["logits_fp32"]) < 1e-6
+        # k_proj.bias has a gradient of (mathematically) zero: its absolute error is held to gtol times the
+        # size of the query bias gradients of the same run, not to a bound that any value would pass
+        qb = max(float(np.abs(g[f"grad_{mode}/{k}"]).max()) for k in grads if "q_proj.bias" in k)
+        num = den = 0.0
         for k, v in grads.items():
             ref = g[f"grad_{mode}/{k}"]
             if "k_proj.bias" in k:
-                assert float(np.abs(v.numpy() - ref).max()) < gtol
+                assert float(np.abs(v.numpy() - ref).max()) < gtol * qb, (mode, k)
             else:
                 assert rel_err(v, ref) < gtol, (mode, k)
+                num += float(((v.numpy().astype(np.float64) - ref) ** 2).sum())
+                den += float((ref.astype(np.float64) ** 2).sum())
+        # the whole gradient is held tighter than any single tensor
+        assert (num / den) ** 0.5 < (2e-6 if mode == "fp32" else 3e-3), mode
 
 
 def test_sampling_golden():
