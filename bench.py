@@ -15,7 +15,7 @@ dropout 0.0 (--dropout; the YAML trains with 0.1, see the "dropout" key of the l
 scaling).  Rank 0 prints ONE JSON line.
 
 The line's "roofline" block is about the kernel class the step spends most of its time in (the
-256-row MFMA GEMM in all its roles); "roofline_by_kernel" lists every instrumented class.  Both
+256-row MFMA GEMMs, eight-wave gemm256_k and four-wave gemm4w_k, in all their roles); "roofline_by_kernel" lists every instrumented class.  Both
 come from HIP events recorded around each launch on the launching stream inside the timed region
 (src/ops.py KERNEL_EVENTS); LDM_BENCH_EVENTS=0 switches the events off (A/B of their cost).
 """
@@ -51,7 +51,7 @@ CONFIGS = {
 # kernel class -> (what bounds it, printable name)
 CLASSES = {
     "gemm.fwd": ("mfma", "gemm256_k forward (qkv, out+residual, gate/up+SwiGLU, down+residual, LM head on masked rows)"),
-    "gemm.dx": ("mfma", "gemm256_k input gradients (incl. the SwiGLU-backward epilogue variant)"),
+    "gemm.dx": ("mfma", "gemm4w_k (plain input gradients over the W^T copies) and gemm256_k (the SwiGLU-backward epilogue variant, LM head)"),
     "gemm.dw": ("mfma", "gemm256_k weight+bias gradients (split-K, fp32 atomics)"),
     "attn.fwd": ("mfma", "attention forward"),
     "attn.bwd": ("mfma", "attention backward (dQ and dK/dV kernels, one entry point)"),
@@ -170,6 +170,8 @@ def main():
                     help="dropout probability of all three dropouts of the encoder layer (attention "
                          "probabilities inside the attention kernels, and the two residual dropouts); "
                          "configs/default.yaml:13 trains with 0.1, parity and the headline number use 0.0")
+    ap.add_argument("--no-dropout-leg", action="store_true",
+                    help="skip the second, shorter timing of the same step at dropout 0.1 (the 'dropout01' key)")
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--objective", default="reference", choices=["reference", "paper"],
                     help="reference: one scalar t per step, unweighted mean over masked positions; paper: "
@@ -271,6 +273,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # Second leg: the same step with the YAML's dropout 0.1 (configs/default.yaml:13) -- attention-probability
+    # dropout inside the attention kernels and the two residual dropouts in the projection epilogues --, on
+    # fewer steps, behind the headline timing and outside it.  Every rank runs it (the collectives match).
+    drop_leg = None
+    if args.dropout == 0.0 and not args.no_dropout_leg:
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.1
+        k2 = max(1, min(args.steps, 5))
+        for _ in range(2):
+            last2 = read(trainer._step(batch))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            last2 = read(trainer._step(batch))
+        sync()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t2 = torch.tensor([e2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            e2 = float(t2.item())
+        drop_leg = {"dropout": 0.1, "steps": k2, "warmup": 2, "ms_per_step": 1e3 * e2 / k2,
+                    "value": args.batch * args.seq * world * k2 / e2, "unit": "tokens/s", "loss_last_step": last2}
+
     if rank == 0:
         tokens = args.batch * args.seq * world * args.steps
         tps = tokens / elapsed
@@ -328,7 +354,7 @@ def main():
             "executed_flops_per_token": fpt_exec, "lm_head_rows_fraction": head_rows,
             "mfma_fraction_attn_plus_gemm": ((g_fl + attn_fl) / ((g_ms + attn_ms) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
                                              if g_ms + attn_ms > 0 else None),
-            "roofline": {"kernel": "gemm256_k, all variants (the time-dominant kernel class of the step)",
+            "roofline": {"kernel": "the 256x256-tile MFMA GEMMs, gemm256_k (all variants) and gemm4w_k (the time-dominant kernel class of the step)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS,
                          "traffic": tj["gemm_bytes_per_launch"] if tj else None,
@@ -337,6 +363,7 @@ def main():
                          "launches_per_step": g_n, "ms_per_step": g_ms,
                          "share_of_step": g_ms / (1e3 * elapsed / args.steps) if elapsed > 0 else None},
             "roofline_by_kernel": by_kernel,
+            "dropout01": drop_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.seq)

@@ -33,7 +33,8 @@ enum {
   LDM_E_ALIGN = -2,    /* pointer or leading dimension not aligned as required */
   LDM_E_SHAPE = -3,    /* shape outside what the kernels support */
   LDM_E_DTYPE = -4,    /* unknown element type */
-  LDM_E_WORKSPACE = -5 /* workspace too small */
+  LDM_E_WORKSPACE = -5,/* workspace too small */
+  LDM_E_COMM = -6      /* RCCL not loadable, or an RCCL call failed: see ldm_comm_last_error() */
 };
 
 int ldm_abi_version(void);
@@ -388,6 +389,31 @@ int ldm_adamw_step_gated(const ldm_adamw_tensor *tensors, int64_t count, int64_t
                          float beta2, float eps, float weight_decay, float grad_scale, const float *gate,
                          const int32_t *skipped, void *stream);
 int ldm_adamw_gate_commit(const float *gate, int32_t *skipped, void *stream);
+
+/* ---------------------------------------------------------------- gradient all-reduce (RCCL)
+ * What DistributedDataParallel does for the reference (main.py:105-108 wraps the model, the bucketed
+ * all-reduce runs inside accelerator.backward, src/trainer.py:136): one process per GPU, a flat bucket
+ * of gradients summed in place over the ranks while backward goes on.
+ * RCCL is found at run time (dlopen; an instance the process already holds -- PyTorch's -- is the one
+ * used; LDM_RCCL_LIB names another file), so a communicator made by the caller's own ncclCommInitRank
+ * can be handed in as `comm` (an ncclComm_t).  The three ldm_comm_* calls make one without touching
+ * RCCL's headers: rank 0 fills a 128-byte id (ldm_comm_unique_id), hands it to the other ranks by any
+ * channel, and every rank calls ldm_comm_init_rank with its GPU current.
+ * ldm_allreduce_bucket: sum of buf[0..count) (dtype LDM_F32 or LDM_BF16, 16-byte aligned) over the
+ *   ranks, in place, queued on comm_stream behind everything producer_stream holds at the call (the
+ *   kernels that wrote the gradients).  Returns at once; calls on one communicator must come in the same
+ *   order on every rank.
+ * ldm_allreduce_join: what consumer_stream gets from now on (the optimizer step) runs behind what
+ *   comm_stream holds now.
+ * Errors: LDM_E_COMM (text in ldm_comm_last_error()), HIP error codes as positive values. */
+int ldm_comm_unique_id(void *id128);
+int ldm_comm_init_rank(void **comm, int nranks, const void *id128, int rank);
+int ldm_comm_size(void *comm, int *nranks);
+int ldm_comm_destroy(void *comm);
+const char *ldm_comm_last_error(void);
+int ldm_allreduce_bucket(void *comm, void *buf, int64_t count, int dtype, void *producer_stream,
+                         void *comm_stream);
+int ldm_allreduce_join(void *comm_stream, void *consumer_stream);
 
 /* ---------------------------------------------------------------- batch producer
  * The batch contract of the training step, {"input_ids", "attention_mask"}: int64 [batch, smax] each

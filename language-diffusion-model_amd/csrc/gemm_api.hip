@@ -131,7 +131,7 @@ extern "C" int ldm_gemm_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, in
                                         ld_qkv, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 17; }
+extern "C" int ldm_abi_version(void) { return 18; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {
@@ -141,6 +141,7 @@ extern "C" const char *ldm_error_string(int code) {
     case LDM_E_SHAPE: return "shape not supported by the kernels";
     case LDM_E_DTYPE: return "unknown element type";
     case LDM_E_WORKSPACE: return "workspace too small";
+    case LDM_E_COMM: return "RCCL not loadable or an RCCL call failed (ldm_comm_last_error() has the text)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }

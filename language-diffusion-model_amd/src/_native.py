@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 17   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 18   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -87,6 +87,13 @@ SIGNATURES = {
     "ldm_adamw_step_gated": (_i32, [C.POINTER(AdamWTensor), _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp,
                                     _vp]),
     "ldm_adamw_gate_commit": (_i32, [_vp, _vp, _vp]),
+    "ldm_comm_unique_id": (_i32, [_vp]),
+    "ldm_comm_init_rank": (_i32, [C.POINTER(_vp), _i32, _vp, _i32]),
+    "ldm_comm_size": (_i32, [_vp, C.POINTER(_i32)]),
+    "ldm_comm_destroy": (_i32, [_vp]),
+    "ldm_comm_last_error": (C.c_char_p, []),
+    "ldm_allreduce_bucket": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "ldm_allreduce_join": (_i32, [_vp, _vp]),
     "ldm_collate_pad": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ldm_synth_tokens": (_i32, [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _u64, _u64, _vp, _vp, _vp]),
     "ldm_gemm_swiglu_bwd": (_i32, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -127,6 +134,8 @@ def lib():
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().ldm_error_string(rc).decode()
+        if rc == -6:
+            msg += ": " + lib().ldm_comm_last_error().decode()
         raise RuntimeError(f"{what} failed with code {rc}: {msg}")
 
 

@@ -13,8 +13,10 @@ Mechanics:
     (LM head and final norm first, embedding last), the order backward produces them;
   * a post-accumulate hook copies each finished gradient into its bucket slice and
     repoints ``param.grad`` at the slice; when a bucket's last gradient arrives its
-    all-reduce is launched asynchronously (RCCL's own stream), so communication of
-    late layers overlaps the backward of early ones;
+    all-reduce is launched asynchronously -- under the RCCL backend through the library's
+    ``ldm_allreduce_bucket`` (ncclAllReduce on a communication stream of this wrapper, joined
+    to the compute stream by events), otherwise through ``torch.distributed`` --, so
+    communication of late layers overlaps the backward of early ones;
   * an engine callback queued on the first hook waits for all buckets at the end of
     backward and applies the 1/world_size scaling; parameters that produced no
     gradient contribute zeros so that ranks stay in lock-step.
@@ -112,6 +114,55 @@ class GradBucketDataParallel(nn.Module):
                     t.data.copy_(h)
                 else:
                     dist.broadcast(t.data, src=src, group=process_group)
+        # RCCL backend: the buckets go through the library's own entry point (ldm_allreduce_bucket: ncclAllReduce
+        # on a communication stream, ordered against the compute stream by events) on a communicator of its
+        # own; torch.distributed stays the channel for set-up and the fallback.  LDM_DP_NATIVE=0 switches it off.
+        self._comm = None
+        self._comm_stream = None
+        if (self._active and dist.get_backend(process_group) == "nccl" and params and params[0].is_cuda
+                and os.environ.get("LDM_DP_NATIVE", "1") != "0"):
+            self._setup_native_comm(params[0].device)
+
+    def _setup_native_comm(self, device):
+        """Create this wrapper's RCCL communicator and prove it with one small all-reduce.  Every rank takes
+        the same decision: if any rank failed, all of them stay on torch.distributed."""
+        import ctypes as C
+        import warnings
+        from . import _native as N
+        lib = N.lib()
+        group = self.process_group
+        rank = dist.get_rank(group)
+        ok, comm, why = 1, C.c_void_p(), ""
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            if lib.ldm_comm_unique_id(buf) == 0:
+                ident[0] = buf.raw
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+        stream = torch.cuda.Stream(device=device)
+        try:
+            if ident[0] is None:
+                raise RuntimeError("rank 0 could not create a communicator id: " + lib.ldm_comm_last_error().decode())
+            with torch.cuda.device(device):
+                N.check(lib.ldm_comm_init_rank(C.byref(comm), self.world_size, ident[0], rank), "ldm_comm_init_rank")
+                probe = torch.ones(64, dtype=torch.float32, device=device)
+                cur = torch.cuda.current_stream(device).cuda_stream
+                N.check(lib.ldm_allreduce_bucket(comm, probe.data_ptr(), probe.numel(), N.F32, cur, stream.cuda_stream),
+                        "ldm_allreduce_bucket")
+                N.check(lib.ldm_allreduce_join(stream.cuda_stream, cur), "ldm_allreduce_join")
+                if not bool((probe == float(self.world_size)).all().item()):
+                    raise RuntimeError("probe all-reduce returned a wrong sum")
+        except Exception as e:       # noqa: BLE001 -- any failure means: use torch.distributed
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            self._comm, self._comm_stream = comm, stream
+        else:
+            if comm.value:
+                lib.ldm_comm_destroy(comm)
+            warnings.warn("native RCCL bucket all-reduce unavailable, using torch.distributed"
+                          + (f" ({why})" if why else " (another rank failed)"))
 
     def _add_bucket(self, params):
         b = _Bucket(list(params), params[0].device, self.wire_dtype)
@@ -160,7 +211,14 @@ class GradBucketDataParallel(nn.Module):
             if b.wire is not None:
                 b.wire.copy_(b.flat)           # one rounding per rank before the sum
                 payload = b.wire
-            if self._host_staged and payload.is_cuda:
+            if self._comm is not None:
+                from . import _native as N
+                b.host = None
+                b.work = None
+                N.check(N.lib().ldm_allreduce_bucket(self._comm, payload.data_ptr(), payload.numel(),
+                                                     N.dtype_code(payload.dtype), N.stream(),
+                                                     self._comm_stream.cuda_stream), "ldm_allreduce_bucket")
+            elif self._host_staged and payload.is_cuda:
                 b.host = payload.cpu()
                 b.work = dist.all_reduce(b.host, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             else:
@@ -181,8 +239,13 @@ class GradBucketDataParallel(nn.Module):
         self._launch_ready()
         self._next = 0
         inv = 1.0 / self.world_size
+        if self._comm is not None:
+            from . import _native as N
+            # the copies, the scaling and the optimizer step queued from here on run behind every bucket's sum
+            N.check(N.lib().ldm_allreduce_join(self._comm_stream.cuda_stream, N.stream()), "ldm_allreduce_join")
         for b in self._buckets:
-            b.work.wait()
+            if b.work is not None:
+                b.work.wait()
             if b.host is not None:
                 (b.wire if b.wire is not None else b.flat).copy_(b.host)
                 b.host = None

@@ -8,7 +8,9 @@ order, 1/W scaling -- is the code the RCCL path runs).
   the per-rank gradients (each rank's loss normalised by its own masked count -- what DDP computes
   for the reference, main.py:105-108 + src/trainer.py:136), dense head in fp32 and fused head in bf16;
 * `python bench.py --gpus 2` typed as a plain command starts its own two ranks and reports
-  ranks_seen = 2."""
+  ranks_seen = 2;
+* RCCL itself with ONE rank: the C-ABI communicator and bucket all-reduce (ldm_comm_*,
+  ldm_allreduce_bucket, ldm_allreduce_join), and the wrapper over the nccl backend taking that path."""
 import os
 import sys
 
@@ -223,3 +225,118 @@ def test_bench_starts_its_own_ranks(dev):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--config",
                           "nonexistent"], env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+# --------------------------------------------------------------------------- RCCL through the C-ABI
+def _rccl_one_rank_worker(q):
+    """ldm_comm_* + ldm_allreduce_bucket on a one-rank communicator: the sum over one rank is the input,
+    so what is checked is that RCCL loads, the communicator comes up, the collective runs on the
+    communication stream BEHIND the kernel that produced the bucket, and the join orders the reader."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import ctypes as C
+    from src import _native as N
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    lib = N.lib()
+    ident = C.create_string_buffer(128)
+    N.check(lib.ldm_comm_unique_id(ident), "ldm_comm_unique_id")
+    comm = C.c_void_p()
+    N.check(lib.ldm_comm_init_rank(C.byref(comm), 1, ident.raw, 0), "ldm_comm_init_rank")
+    n = C.c_int(0)
+    N.check(lib.ldm_comm_size(comm, C.byref(n)), "ldm_comm_size")
+    assert n.value == 1
+    side = torch.cuda.Stream(device=dev)
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        big = torch.randn(64 << 20, device=dev)                 # a long producer kernel in front of the collective
+        buf = torch.zeros(1 << 20, dtype=dt, device=dev)
+        cur = torch.cuda.current_stream().cuda_stream
+        big.mul_(1.0001)
+        buf.copy_(torch.arange(1 << 20, device=dev) % 251)       # written on the compute stream
+        want = buf.clone()
+        N.check(lib.ldm_allreduce_bucket(comm, buf.data_ptr(), buf.numel(), N.dtype_code(dt), cur, side.cuda_stream),
+                "ldm_allreduce_bucket")
+        N.check(lib.ldm_allreduce_join(side.cuda_stream, cur), "ldm_allreduce_join")
+        got = buf * 2                                             # a reader on the compute stream
+        torch.cuda.synchronize()
+        out[str(dt)] = bool(torch.equal(got, want * 2))
+    # argument checks answer without touching RCCL
+    assert lib.ldm_allreduce_bucket(comm, 8, 4, 7, None, None) == -4          # dtype
+    assert lib.ldm_allreduce_bucket(None, 16, 4, 0, None, None) == -1
+    assert lib.ldm_allreduce_bucket(comm, 8, 4, 0, None, None) == -2          # alignment
+    N.check(lib.ldm_comm_destroy(comm), "ldm_comm_destroy")
+    q.put(out)
+
+
+def test_rccl_bucket_allreduce_through_the_c_abi_one_rank(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=170)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert out == {"torch.float32": True, "torch.bfloat16": True}, out
+
+
+def _native_dp_worker(port, q):
+    """The data-parallel wrapper over the RCCL backend with one rank (LDM_DP_FORCE=1): the buckets go
+    through ldm_allreduce_bucket; three trainer steps must equal the plain single-process run."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LDM_DP_FORCE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import random
+    import types
+    from src.dp import GradBucketDataParallel, HipAccelerator
+    from src.masking_strategy import create_masking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.optim import FusedAdamW
+    from src.trainer import DiffusionLanguageModelTrainer
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    res = {}
+    for wire in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        random.seed(0)
+        tr = DiffusionTransformer(DiffusionTransformerConfig(vocab_size=500, d_model=64, nhead=2, num_layers=2,
+                                                             dim_feedforward=128, dropout=0.0, layer_norm_eps=1e-12,
+                                                             max_position_embeddings=64))
+        tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+        model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
+        acc = HipAccelerator(mixed_precision="no", device=dev, bucket_bytes=64 << 10, grad_wire_dtype=wire)
+        model = acc.prepare(model)
+        assert isinstance(model, GradBucketDataParallel) and model._comm is not None and model.num_buckets >= 2
+        opt = acc.prepare(FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.1))
+        trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(110, 500, (4, 32), generator=g)
+        ids[:, 0], ids[:, -1] = 101, 102
+        batch = {"input_ids": ids.to(dev), "attention_mask": torch.ones_like(ids).to(dev)}
+        random.seed(3)
+        torch.manual_seed(3)
+        losses = [trainer.loss_value(trainer._step(batch)) for _ in range(3)]
+        res[str(wire)] = (losses, {n: p.detach().cpu().numpy() for n, p in model.module.named_parameters()})
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_wrapper_over_rccl_backend_uses_the_native_allreduce(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    p = ctx.Process(target=_native_dp_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=170)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    ref_losses, ref_params = _run_steps(dev, False)
+    for wire, (losses, params) in res.items():
+        tol = 1e-5 if wire == "torch.float32" else 2e-2
+        assert np.allclose(losses, ref_losses, rtol=tol), (wire, losses, ref_losses)
+        for n, v in ref_params.items():
+            err = np.linalg.norm(params[n] - v) / max(np.linalg.norm(v), 1e-30)
+            assert err < (1e-4 if wire == "torch.float32" else 2e-2), (wire, n, err)

@@ -412,3 +412,143 @@ def test_8b_layer_shape_two_layers(dev):
             continue
         assert rel_err(res["fused"][1][n], gd) < 5e-3, n
         assert rel_err(res["recompute"][1][n], res["fused"][1][n]) < 5e-3, n
+
+
+def _device_model(cfg_kwargs, dev, max_pos, seed):
+    """A model of the given shape created ON the device (the weights of the large shapes are never on
+    the host): the constructor's own initialisation (src/transformer.py:407-411 of the reference)."""
+    from src.masking_strategy import create_masking_strategy
+    from src.model import DiffusionLanguageModel
+    from src.transformer import DiffusionTransformer, DiffusionTransformerConfig
+    torch.manual_seed(seed)
+    with torch.device(dev):
+        tr = DiffusionTransformer(DiffusionTransformerConfig(dropout=0.0, layer_norm_eps=1e-12,
+                                                             max_position_embeddings=max_pos, **cfg_kwargs))
+    tr.to(dev)
+    tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
+    return DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None).train()
+
+
+def test_1b_full_depth_seq_4096_properties(dev):
+    """The ~1B model at its full 16 layers AND the long sequence (S=4096, B=2, one padded tail): too large
+    for the host oracle in test time, so the size-independent properties -- loss near ln(V) at random
+    init, fused head loss == dense composition, activation recompute changes nothing, every gradient
+    finite and non-zero."""
+    from src.loss import variational_lower_bound_loss
+    V = 32000
+    model = _device_model(dict(vocab_size=V, d_model=2048, nhead=16, num_layers=16, dim_feedforward=5632), dev, 4096, 41)
+    model.transformer.set_compute_dtype(torch.bfloat16)
+    S = 4096
+    g = torch.Generator().manual_seed(42)
+    ids = torch.randint(1000, V, (2, S), generator=g)
+    ids[:, 0] = 101
+    att = torch.ones(2, S, dtype=torch.long)
+    att[1, 3000:] = 0
+    ids[1, 2999] = 102
+    ids = torch.where(att == 1, ids, torch.zeros_like(ids)).to(dev)
+    att = att.to(dev)
+    tr = model.transformer
+    res = {}
+    for kind in ("fused", "dense", "recompute"):
+        tr.recompute_layers = kind == "recompute"
+        tr.zero_grad(set_to_none=True)
+        torch.manual_seed(7)                       # same mask draw in every run
+        if kind == "dense":
+            logits, masked, _ = model(ids, att, t=torch.tensor([0.3]))
+            l = variational_lower_bound_loss(logits, ids, masked, 103, att)
+            del logits
+        else:
+            l = model.training_loss(ids, att, t=torch.tensor([0.3]))
+        l.backward()
+        res[kind] = (l.item(), {n: p.grad.detach().clone() for n, p in tr.named_parameters()})
+        del l
+        torch.cuda.empty_cache()
+    assert abs(res["fused"][0] - math.log(V)) < 1.5
+    assert abs(res["fused"][0] - res["dense"][0]) <= 1e-5 * abs(res["dense"][0])
+    assert res["fused"][0] == res["recompute"][0]
+    for n, gd in res["dense"][1].items():
+        assert bool(torch.isfinite(gd).all()), n
+        if n.endswith("k_proj.bias"):
+            continue
+        assert float(gd.abs().max()) > 0, n
+        # fused and dense head differ in where the head's input gradient is rounded to bf16; sixteen layers
+        # down, the small q/k projection gradients carry that as ~5e-3 (measured: layers.0 k_proj.weight
+        # 5.1e-3), so the two are held to the bf16 bound of the step, the recompute run (same arithmetic,
+        # float-atomic order only) to 5e-3
+        assert rel_err(res["fused"][1][n], gd) < 2e-2, n
+        assert rel_err(res["recompute"][1][n], res["fused"][1][n]) < 5e-3, n
+
+
+def _deep_8b_worker(port, q):
+    """LLaDA-8B layer shape at the deepest layer count this GPU holds (32 = the full model when ~210 GB
+    are free), trained the way an 8-GPU node would hold it: activation recompute, bf16 gradient wire,
+    bucketed all-reduce (one-rank RCCL communicator, LDM_DP_FORCE=1), FusedAdamW."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LDM_DP_FORCE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from src.dp import GradBucketDataParallel, HipAccelerator
+    from src.optim import FusedAdamW
+    from src.trainer import DiffusionLanguageModelTrainer
+    V, d, F = 126464, 4096, 12288
+    free, total = torch.cuda.mem_get_info()
+    # bytes that stay allocated per parameter: fp32 master 4, bf16 copy 2, transposed bf16 copy 2, bucket 4,
+    # bf16 wire 2, both moments 8; plus the step's weight-gradient pool 4 while backward runs
+    per_param = 4 + 2 + 2 + 4 + 2 + 8 + 4
+    layer = 4 * d * d + 3 * d * F
+    fixed = 2 * V * d * per_param + (24 << 30)            # embedding + LM head, activations and slack
+    layers = int(max(1, min(32, (free - fixed) // (layer * per_param))))
+    model = _device_model(dict(vocab_size=V, d_model=d, nhead=32, num_layers=layers, dim_feedforward=F), dev, 4096, 51)
+    model.transformer.recompute_layers = True
+    acc = HipAccelerator(mixed_precision="bf16", device=dev, bucket_bytes=256 << 20, grad_wire_dtype=torch.bfloat16)
+    model = acc.prepare(model)
+    assert isinstance(model, GradBucketDataParallel) and model._comm is not None
+    opt = acc.prepare(FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.1))
+    trainer = DiffusionLanguageModelTrainer(model, opt, None, acc)
+    S = 4096
+    g = torch.Generator().manual_seed(52)
+    ids = torch.randint(1000, V, (1, S), generator=g)
+    ids[:, 0] = 101
+    batch = {"input_ids": ids.to(dev), "attention_mask": torch.ones_like(ids).to(dev)}
+    import random
+    random.seed(5)
+    torch.manual_seed(5)
+    w0 = model.module.transformer.layers[layers - 1].swiglu.w3.weight.detach()[:4, :64].clone()
+    losses = []
+    for _ in range(2):
+        losses.append(trainer.loss_value(trainer._step(batch)))
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    w1 = model.module.transformer.layers[layers - 1].swiglu.w3.weight.detach()[:4, :64]
+    n_params = sum(p.numel() for p in model.module.parameters())
+    q.put(dict(layers=layers, losses=losses, buckets=model.num_buckets, params=n_params,
+               peak_gb=torch.cuda.max_memory_allocated() / 2 ** 30, free_gb=free / 2 ** 30,
+               changed=bool((w1 != w0).any().item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1000)
+def test_8b_shape_at_the_depth_one_gpu_holds_with_recompute_and_bf16_wire(dev):
+    import gc
+    import os
+    import torch.multiprocessing as mp
+    gc.collect()
+    torch.cuda.empty_cache()          # what this process still caches is not free for the worker
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 2000)
+    p = ctx.Process(target=_deep_8b_worker, args=(port, q))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    print(f"[8b-deep] {out}")
+    assert out["layers"] >= 16, out                    # an MI355X holds the full 32
+    assert all(math.isfinite(l) for l in out["losses"]) and abs(out["losses"][0] - math.log(126464)) < 1.5, out
+    assert out["changed"] and out["buckets"] >= out["layers"], out
