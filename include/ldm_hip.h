@@ -315,8 +315,12 @@ int ldm_ce_bwd(const void *logits, int dtype, int64_t ld, int64_t T, int64_t V, 
  *                         dlogits [T, ld_d]; rows count..roundup(count,64) are zeroed
  *   ldm_gather_rows     : out[i,:] = x[rows[i],:] (same zero rounding rows); out has
  *                         roundup(max_rows,64) rows
+ *   ldm_scatter_rows    : out[rows[i],:] = x[i,:] for i < *count (x has max_rows rows, out has
+ *                         out_rows; the other rows of out are left as they are)
  *   ldm_gemm_rows_dyn   : C[row_map[m], :] = A[m, :K] * opB(B) (+ bias) for m < *m_dev; row_map may
- *                         be NULL (identity), bias may be NULL                 (BF16, MFMA)
+ *                         be NULL (identity), bias may be NULL                 (BF16, MFMA).
+ *                         A holds all M rows (rows >= *m_dev may be read, their products are dropped);
+ *                         rows >= *m_dev of C are not written
  *   ldm_gemm_acc_kdyn   : C(fp32) += opA(A) * opB(B) with K = roundup(*k_dev, 32) (BF16, MFMA);
  *                         a_rowsum (nullable) as in ldm_gemm_acc_rowsum
  *   ldm_colsum_rows_dyn : ldm_colsum over the first *m_dev rows
@@ -330,6 +334,8 @@ int ldm_ce_bwd_compact(const void *logits, int dtype, int64_t ld, int64_t T, int
                        void *dlogits, int64_t ld_d, void *stream);
 int ldm_gather_rows(const void *x, int dtype, int64_t ld, const int32_t *rows, const int32_t *count,
                     int64_t max_rows, int64_t d, void *out, void *stream);
+int ldm_scatter_rows(const void *x, int dtype, int64_t ld, const int32_t *rows, const int32_t *count,
+                     int64_t max_rows, int64_t out_rows, int64_t d, void *out, int64_t ld_out, void *stream);
 int ldm_gemm_rows_dyn(int out_dtype, int transB, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                       const void *B, int64_t ldb, void *C, int64_t ldc, const float *bias, const int32_t *m_dev,
                       const int32_t *row_map, void *stream);

@@ -628,6 +628,21 @@ __global__ __launch_bounds__(256) void gather_rows_k(const T *x, int64_t ld, con
   for (int64_t c = lane * 4; c < d; c += 256) st4(dst + c, ld4(src + c));
 }
 
+// out[rows[i], :] = x[i, :] for i < count (the inverse of gather_rows_k; the other rows of out are left alone)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_k(const T *x, int64_t ld, const int *rows, const int *count,
+                                                      int64_t out_rows, int64_t d, T *out, int64_t ld_out) {
+  const int cnt = count[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per source row
+  if (i >= cnt) return;
+  const int64_t r = rows[i];
+  if (r < 0 || r >= out_rows) return;
+  const T *src = x + i * ld;
+  T *dst = out + r * ld_out;
+  for (int64_t c = lane * 4; c < d; c += 256) st4(dst + c, ld4(src + c));
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_k(const float *src, bf16_t *dst, int64_t n4,
                                                        int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
@@ -1044,6 +1059,24 @@ static inline int64_t colsum_slices(int64_t M) {
 }
 
 extern "C" int64_t ldm_colsum_ws_floats(int64_t M, int64_t N) { return colsum_slices(M) * N; }
+
+extern "C" int ldm_scatter_rows(const void *x, int dtype, int64_t ld, const int32_t *rows, const int32_t *count,
+                                int64_t max_rows, int64_t out_rows, int64_t d, void *out, int64_t ld_out, void *stream) {
+  if (max_rows < 0 || out_rows < 0 || d <= 0 || ld < d || ld_out < d) return LDM_E_BADARG;
+  if (max_rows == 0 || out_rows == 0) return LDM_OK;
+  if (!x || !rows || !count || !out) return LDM_E_BADARG;
+  if (d % 4 || ld % 4 || ld_out % 4) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(out, 16)) return LDM_E_ALIGN;
+  const unsigned grid = (unsigned)ceil_div(max_rows, 4);
+  if (dtype == LDM_F32)
+    hipLaunchKernelGGL(scatter_rows_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, ld, rows, count, out_rows, d, (float *)out, ld_out);
+  else if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(scatter_rows_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ld, rows, count, out_rows, d, (bf16_t *)out, ld_out);
+  else
+    return LDM_E_DTYPE;
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
 
 static int colsum_impl(const void *X, int dtype, int64_t M, int64_t N, int64_t ld, float *out, float *ws,
                        const int *m_dev, void *stream);

@@ -31,7 +31,9 @@
 // an odd step first waits (counted vmcnt) for the pair that the next two steps read.
 //
 // Takes: A [M, K] and B [N, K] both K-contiguous, bf16 output, M and N multiples of 256, K a multiple of 64
-// and at least 320, optional fp32 bias.  Everything else stays with gemm_mfma256.hip.
+// and at least 320, optional fp32 bias, optionally a device-side row count (whole 256-row tiles are computed
+// from whatever A holds; the rows of C at and beyond the count are not written).  Everything else stays with
+// gemm_mfma256.hip.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -60,6 +62,7 @@ struct WArgs {
   const bf16_t *B; int64_t ldb;
   bf16_t *C; int64_t ldc;
   const float *bias;
+  const int *dyn_m;   // nullable: device-side row count; only the m-tiles that hold rows < *dyn_m are walked
   int tiles_m, tiles_n, band_m;
 };
 
@@ -104,7 +107,16 @@ template <int V> using IC = std::integral_constant<int, V>;
 template <int WR>
 __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
   constexpr int wave = WR, wm = WR >> 1, wn = WR & 1;
-  const int total = g.tiles_m * g.tiles_n;
+  int tiles_m = g.tiles_m;
+  int mdyn = 0x7fffffff;   // rows of C that exist (device-side count)
+  if (g.dyn_m) {
+    // (a scalar load, written out: the count and everything derived from it stay in scalar registers)
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mdyn) : "s"(g.dyn_m) : "memory");
+    const int td = (mdyn + BM - 1) / BM;
+    tiles_m = td < tiles_m ? (td > 0 ? td : 0) : tiles_m;
+  }
+
+  const int total = tiles_m * g.tiles_n;
   const int np = (int)(g.K / KH);
   int w = blockIdx.x;
   if (w >= total) return;
@@ -170,7 +182,7 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 0" ::"v"(q), "v"(vo), "s"(srd), "s"(soff), "n"(t * 64) : "memory");
   };
 
-  TileId tid = decode_item(w, total, g.tiles_m, g.tiles_n, g.band_m);
+  TileId tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
   prologue(tid);
   bool first_item = true;
 
@@ -302,7 +314,7 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     w += gridDim.x;
     const bool more = w < total;
     if (more) {
-      tid = decode_item(w, total, g.tiles_m, g.tiles_n, g.band_m);
+      tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
       prologue(tid);
     }
     if (has_bias) {
@@ -322,7 +334,13 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
       i4s_t srd;
       srd[0] = (int)(uintptr_t)cb;
       srd[1] = (int)(((uintptr_t)cb >> 32) & 0xffff);
-      srd[2] = -1;
+      // rows at and beyond the device-side count are not written: the descriptor ends with the last valid row
+      // of this wave's block (a row is at least 512 bytes apart from the next, a block row 256 bytes long).
+      // (The tile coordinates come out of an integer division, i.e. of the vector unit: the result is pinned
+      // to a scalar register.)
+      int left = mdyn - (int)(m0 + wm * 128);
+      left = left < 0 ? 0 : (left > 128 ? 128 : left);
+      srd[2] = __builtin_amdgcn_readfirstlane(mdyn == 0x7fffffff ? -1 : left * (int)(g.ldc * 2));
       srd[3] = 0x00020000;
       // out of the accumulation registers HERE (left to the compiler, all 256 are copied out at once, right
       // behind the loop, and the vector registers spill)
@@ -396,9 +414,10 @@ bool ldm_gemm_4w_enabled() {
 }
 
 // C[M, N] (bf16) = A[M, K] * B[N, K]^T (+ bias[N]).  LDM_E_SHAPE / LDM_E_ALIGN for what the kernel does not
-// take (the caller then runs the eight-wave kernel).
+// take (the caller then runs the eight-wave kernel).  dyn_m (nullable): device-side row count <= M; A and C
+// must hold all M rows.
 int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb,
-                         void *C, int64_t ldc, const float *bias, hipStream_t s) {
+                         void *C, int64_t ldc, const float *bias, const int *dyn_m, hipStream_t s) {
   if (M < 256 || M % 256 || N < 256 || N % 256) return LDM_E_SHAPE;
   if (K % 64 || K < (int64_t)(NSS + 4) * KH) return LDM_E_SHAPE;
   if (lda % 8 || ldb % 8 || ldc % 8 || lda < K || ldb < K || ldc < N) return LDM_E_ALIGN;
@@ -411,6 +430,7 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
   g.M = M; g.N = N; g.K = K;
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb; g.C = (bf16_t *)C; g.ldc = ldc;
   g.bias = bias;
+  g.dyn_m = dyn_m;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn;
   {
     // m-tiles per band of the tile walk: at most 8, fewer while the band's A panel exceeds 8 MB (measured at

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 18   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 19   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -98,6 +98,7 @@ SIGNATURES = {
     "ldm_synth_tokens": (_i32, [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _u64, _u64, _vp, _vp, _vp]),
     "ldm_gemm_swiglu_bwd": (_i32, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ldm_gather_rows": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "ldm_scatter_rows": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "ldm_gemm_rows_dyn": (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                  _vp]),
     "ldm_gemm_acc_kdyn": (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),

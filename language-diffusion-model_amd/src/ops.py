@@ -96,7 +96,11 @@ DX_TRANSPOSED_WEIGHTS = os.environ.get("LDM_DX_WT", "1") != "0"
 
 
 class PackedWeights:
-    def __init__(self, weights, biases, dtype: torch.dtype, name: str = "linear"):
+    def __init__(self, weights, biases, dtype: torch.dtype, name: str = "linear", pad: int = PAD_N):
+        """``pad``: the packed copies hold the output columns padded (zero rows / zero bias) to this multiple
+        of PAD_N; the vocabulary projection pads to 256 so that its products are whole 256-wide tiles."""
+        if pad % PAD_N:
+            raise ValueError(f"pad must be a multiple of {PAD_N}")
         self.name = name
         self.compact_rows = name == "head"   # its gradient comes from the masked CE: mostly zero rows
         self.weights = list(weights)
@@ -105,7 +109,7 @@ class PackedWeights:
         self.n_each = [int(w.shape[0]) for w in self.weights]
         self.n = sum(self.n_each)
         self.k = int(self.weights[0].shape[1])
-        self.n_pad = _round_up(self.n, PAD_N)
+        self.n_pad = _round_up(self.n, pad)
         self._key = None
         self.w = None
         self.b = None
@@ -419,6 +423,37 @@ class _PackedLinear(torch.autograd.Function):
         return (dx, dres, None, None, None, None, *grads_w, *grads_b)
 
 
+def _compact_input_grad(pack, gc, rows, count, T, k, w):
+    """dx [T, k] of a projection from COMPACT output-gradient rows: row rows[i] of dx = gc[i] @ W for
+    i < *count, every other row zero.  With the transposed weight copy the product is computed compact
+    (both operands read along the reduction, the four-wave kernel's form) and its rows are then moved to
+    their places by one scatter pass; otherwise the GEMM's mapped-row form writes them directly."""
+    lib = N.lib()
+    st = N.stream()
+    n_pad = pack.n_pad
+    dev = gc.device
+    dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
+    rows_alloc = gc.shape[0]
+    wt = pack.get_t() if (DX_TRANSPOSED_WEIGHTS and rows_alloc % 256 == 0 and k % 256 == 0 and n_pad % 64 == 0) else None
+    if wt is not None:
+        dxc = torch.empty(rows_alloc, k, dtype=torch.bfloat16, device=dev)
+        with _Timed("gemm.dx", 2.0 * k * n_pad, count):
+            rc = lib.ldm_gemm_rows_dyn(N.BF16, 1, rows_alloc, k, n_pad, gc.data_ptr(), n_pad, wt.data_ptr(), n_pad,
+                                       dxc.data_ptr(), k, None, count.data_ptr(), None, st)
+        if rc not in (-2, -3):
+            N.check(rc, "ldm_gemm_rows_dyn")
+            N.check(lib.ldm_scatter_rows(dxc.data_ptr(), N.BF16, k, rows.data_ptr(), count.data_ptr(), rows_alloc, T, k,
+                                         dx.data_ptr(), k, st), "ldm_scatter_rows")
+            return dx
+    with _Timed("gemm.dx", 2.0 * k * n_pad, count):
+        rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, gc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
+                                   None, count.data_ptr(), rows.data_ptr(), st)
+    if rc in (-2, -3):
+        return None
+    N.check(rc, "ldm_gemm_rows_dyn")
+    return dx
+
+
 def _backward_compact(ctx, x2, w, dlc, rows, count):
     """dx, dW, db of a projection from the compact gradient rows (None if the kernels decline)."""
     pack = ctx.pack
@@ -430,13 +465,9 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
     st = N.stream()
     dx = None
     if ctx.needs_input_grad[0]:
-        dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
-        with _Timed("gemm.dx", 2.0 * k * n_pad, count):
-            rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, dlc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
-                                       None, count.data_ptr(), rows.data_ptr(), st)
-        if rc in (-2, -3):
+        dx = _compact_input_grad(pack, dlc, rows, count, T, k, w)
+        if dx is None:
             return None
-        N.check(rc, "ldm_gemm_rows_dyn")
     xc = torch.empty(Tp, k, dtype=torch.bfloat16, device=dev)
     N.check(lib.ldm_gather_rows(x2.data_ptr(), N.BF16, x2.stride(0), rows.data_ptr(), count.data_ptr(), T, k,
                                 xc.data_ptr(), st), "ldm_gather_rows")
@@ -997,7 +1028,7 @@ class _MaskedCE(torch.autograd.Function):
             link = None
         ctx.link = link
         if (link is not None and link.compact_ok and l2.dtype == torch.bfloat16 and T > 1 and ld % PAD_N == 0
-                and ld == _round_up(V, PAD_N)):
+                and ld >= V):
             rows = torch.empty(T, dtype=torch.int32, device=dev)
             cnt = torch.empty(1, dtype=torch.int32, device=dev)
             N.check(lib.ldm_ce_compact_rows(T, seq, N.ptr(mi), int(mask_token_id), N.ptr(mb), N.ptr(av),
@@ -1015,12 +1046,14 @@ class _MaskedCE(torch.autograd.Function):
         mi, mb, av, sw, mask_token_id, norm_mode, seq, ld, shape, in_dtype = ctx.aux
         lib = N.lib()
         T, V = l2.shape
-        Vp = _round_up(V, PAD_N)
         g = gout.reshape(1).float().contiguous()
         link = ctx.link
+        # row stride of the gradient: that of the projection's output when the logits came straight from it
+        # (its backward then takes the buffer as it is), else V rounded up to the padding unit
+        Vp = ld if (link is not None and ld % PAD_N == 0 and ld >= V) else _round_up(V, PAD_N)
         if ctx.compact is not None:
             rows, cnt = ctx.compact
-            dlc = torch.empty(_round_up(T, 64), Vp, dtype=l2.dtype, device=l2.device)
+            dlc = torch.empty(_round_up(T, 256), Vp, dtype=l2.dtype, device=l2.device)
             N.check(lib.ldm_ce_bwd_compact(l2.data_ptr(), N.dtype_code(l2.dtype), ld, T, V, seq, tg.data_ptr(),
                                            N.ptr(sw), norm_mode, lse.data_ptr(), out[1:2].data_ptr(), g.data_ptr(),
                                            rows.data_ptr(), cnt.data_ptr(), dlc.data_ptr(), Vp, N.stream()),
@@ -1099,7 +1132,8 @@ class _HeadMaskedCE(torch.autograd.Function):
         norm_T = float(T)
         lc = torch.empty(Tp, n_pad, dtype=torch.bfloat16, device=dev)
         with _Timed("gemm.fwd", 2.0 * n_pad * k, cnt):              # flops per row; rows = cnt (device)
-            N.check(lib.ldm_gemm_rows_dyn(N.BF16, 1, T, n_pad, k, xc.data_ptr(), k, w.data_ptr(), k, lc.data_ptr(), n_pad,
+            # (M = the rows the compact buffers hold, a multiple of 256: whole tiles for the four-wave kernel)
+            N.check(lib.ldm_gemm_rows_dyn(N.BF16, 1, Tp, n_pad, k, xc.data_ptr(), k, w.data_ptr(), k, lc.data_ptr(), n_pad,
                                           b.data_ptr(), cnt.data_ptr(), None, st), "ldm_gemm_rows_dyn")
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         tmp = torch.empty(T, dtype=torch.float32, device=dev)
@@ -1154,10 +1188,9 @@ class _HeadMaskedCE(torch.autograd.Function):
                     "ldm_ce_bwd_compact")
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros(T, k, dtype=torch.bfloat16, device=dev)
-            with _Timed("gemm.dx", 2.0 * k * n_pad, cnt):
-                N.check(lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, lc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(),
-                                              k, None, cnt.data_ptr(), rows.data_ptr(), st), "ldm_gemm_rows_dyn")
+            dx = _compact_input_grad(pack, lc, rows, cnt, T, k, w)
+            if dx is None:
+                raise RuntimeError("ldm_gemm_rows_dyn declined the LM-head input gradient")
         dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
         dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
         with _Timed("gemm.dw", 2.0 * n_pad * k, cnt):

@@ -305,7 +305,10 @@ class DiffusionTransformer(nn.Module):
     def _head_pack(self) -> ops.PackedWeights:
         key = self.compute_dtype
         if key not in self._packs:
-            self._packs[key] = ops.PackedWeights([self.output_layer.weight], [self.output_layer.bias], key, "head")
+            # padded to whole 256-column tiles (30522 -> 30720): the head's products then run on the four-wave
+            # GEMM; the padding columns are zero weights and zero bias, and the loss kernels skip them
+            self._packs[key] = ops.PackedWeights([self.output_layer.weight], [self.output_layer.bias], key, "head",
+                                                 pad=256)
         return self._packs[key]
 
     def hidden_states(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:

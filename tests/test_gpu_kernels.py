@@ -662,6 +662,44 @@ def test_gemm_rows_dyn_many_tiles(dev):
     assert rel_err(c2.float(), want) < 4e-3
 
 
+@pytest.mark.parametrize("cnt_v", [9000, 0, 1, 12288, 8960, 12161])
+def test_gemm_rows_dyn_four_wave_keeps_rows_past_the_count(dev, cnt_v):
+    """The device-side row count on the four-wave kernel (K >= 320, whole tiles, no row map): whole tiles
+    are computed, the rows of C at and beyond the count stay as they were (counts inside a wave's 128-row
+    block, on its edge, zero, one, all)."""
+    from src import _native as Nn
+    torch.manual_seed(8)
+    M, N, K = 12288, 768, 2048
+    a = torch.randn(M, K, device=dev).bfloat16()
+    a[cnt_v:] = float("nan")                       # rows past the count may be read, never used
+    w = torch.randn(N, K, device=dev).bfloat16()
+    bias = torch.randn(N, device=dev)
+    cnt = torch.tensor([cnt_v], dtype=torch.int32, device=dev)
+    c = torch.full((M + 256, N), 7.0, dtype=torch.bfloat16, device=dev)
+    Nn.check(Nn.lib().ldm_gemm_rows_dyn(1, 1, M, N, K, a.data_ptr(), K, w.data_ptr(), K, c.data_ptr(), N,
+                                        bias.data_ptr(), cnt.data_ptr(), None, Nn.stream()), "rows_dyn")
+    if cnt_v:
+        ref = a[:cnt_v].double() @ w.double().t() + bias.double()
+        assert rel_err(c[:cnt_v].float(), ref) < 4e-3
+    assert bool((c[cnt_v:] == 7.0).all()), "rows past the device-side count must not be written"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scatter_rows(dev, dtype):
+    from src import _native as Nn
+    torch.manual_seed(9)
+    T, d, cnt_v = 5000, 768, 3111
+    x = torch.randn(4096, d, device=dev).to(dtype)
+    rows = torch.randperm(T, device=dev)[:4096].to(torch.int32)
+    cnt = torch.tensor([cnt_v], dtype=torch.int32, device=dev)
+    out = torch.full((T, d), 3.0, device=dev).to(dtype)
+    Nn.check(Nn.lib().ldm_scatter_rows(x.data_ptr(), Nn.dtype_code(dtype), d, rows.data_ptr(), cnt.data_ptr(), 4096, T, d,
+                                       out.data_ptr(), d, Nn.stream()), "ldm_scatter_rows")
+    want = torch.full((T, d), 3.0, device=dev).to(dtype)
+    want[rows[:cnt_v].long()] = x[:cnt_v]
+    assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("rows,V,count", [(128, 30522, 100), (64, 2051, 64), (256, 32000, 0), (64, 40000, 37),
