@@ -236,6 +236,9 @@ def main():
     batch = {"input_ids": ids.to(dev), "attention_mask": att.to(dev)}
 
     def sync():
+        # device first: the gradient all-reduces of the last step (the data-parallel wrapper's own RCCL
+        # communicator) have completed before the barrier's collective (torch.distributed's) starts
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -55,4 +55,4 @@ int ldm_gemm_mfma256_bf16_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, 
 // optional bias; LDM_E_SHAPE / LDM_E_ALIGN for anything else
 bool ldm_gemm_4w_enabled();
 int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb,
-                         void *C, int64_t ldc, const float *bias, const int *dyn_m, hipStream_t s);
+                         void *C, int64_t ldc, const float *bias, const void *R, const int *dyn_m, hipStream_t s);

@@ -1186,9 +1186,9 @@ double quant_eff(int64_t tiles) { return (double)tiles / (double)(ceil_div(tiles
 int ldm_gemm_mfma256_bf16(int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                           const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc,
                           const float *bias, const void *R, int64_t ldr, hipStream_t s) {
-  // the four-wave kernel takes what it can (K-contiguous operands, full tiles, no residual)
-  if (ldm_gemm_4w_enabled() && out_dtype == LDM_BF16 && !transA && transB && !R && alpha == 1.0f) {
-    const int rc4 = ldm_gemm_mfma4w_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, s);
+  // the four-wave kernel takes what it can (K-contiguous operands, full tiles; a bf16 residual with C's row stride)
+  if (ldm_gemm_4w_enabled() && out_dtype == LDM_BF16 && !transA && transB && (!R || ldr == ldc) && alpha == 1.0f) {
+    const int rc4 = ldm_gemm_mfma4w_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, R, nullptr, s);
     if (rc4 != LDM_E_SHAPE && rc4 != LDM_E_ALIGN) return rc4;
   }
   MArgs g;
@@ -1318,7 +1318,7 @@ int ldm_gemm_mfma256_bf16_dyn(int out_dtype, int transA, int transB, int64_t M, 
   // apart) it measured 7 % SLOWER than the eight-wave kernel (6.35 against 5.91 ms mean over the same seven
   // steps), at its input-gradient shape (N = 768, K = 30720) 11 % faster (7.8 against 8.8 ms at the same count)
   if (ldm_gemm_4w_enabled() && out_dtype == LDM_BF16 && !transA && transB && !row_map && alpha == 1.0f && K >= 2048) {
-    const int rc4 = ldm_gemm_mfma4w_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, dyn_m, s);
+    const int rc4 = ldm_gemm_mfma4w_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, dyn_m, s);
     if (rc4 != LDM_E_SHAPE && rc4 != LDM_E_ALIGN) return rc4;
   }
   MArgs g;

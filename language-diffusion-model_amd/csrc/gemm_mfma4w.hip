@@ -62,6 +62,7 @@ struct WArgs {
   const bf16_t *B; int64_t ldb;
   bf16_t *C; int64_t ldc;
   const float *bias;
+  const bf16_t *R;    // nullable: residual [M, N] with the row stride of C, added before the rounding to bf16
   const int *dyn_m;   // nullable: device-side row count; only the m-tiles that hold rows < *dyn_m are walked
   int tiles_m, tiles_n, band_m;
 };
@@ -104,7 +105,7 @@ __device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int
 template <int V> using IC = std::integral_constant<int, V>;
 
 // WR: the wave (0..3); wave (wm, wn) = (WR >> 1, WR & 1) owns rows wm * 128.., columns wn * 128.. of the tile
-template <int WR>
+template <int WR, bool RESID>
 __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
   constexpr int wave = WR, wm = WR >> 1, wn = WR & 1;
   int tiles_m = g.tiles_m;
@@ -182,6 +183,18 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 0" ::"v"(q), "v"(vo), "s"(srd), "s"(soff), "n"(t * 64) : "memory");
   };
 
+  // residual quad j of the current item: the 16 rows x 64 bytes that store j of this item will cover, requested
+  // with the store's own lane offset from a scalar pointer that walks down the wave's block 16 rows at a time.
+  // The data is in pk[j] only behind a counted wait; until then nothing touches those registers.
+  [[maybe_unused]] const char *rptr = nullptr;
+  [[maybe_unused]] auto res_load = [&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const unsigned vo = lane_st;
+    const char *base = rptr;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(pk[j]) : "v"(vo), "s"(base), "n"((j % 4) * 64) : "memory");
+    if constexpr (j % 4 == 3) rptr += ldc16;
+  };
+
   TileId tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
   prologue(tid);
   bool first_item = true;
@@ -211,17 +224,21 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     // One 32-deep step: MFMAs on the fragments of half-tile p (set cur) with, in the gaps, the reads of
     // half-tile p+1 (set nxt), this step's LDS-DMA and deferred stores.
     //   PAR = p & 1; FIRST: step 0 (C = 0); ISSUE: the step sends LDS-DMA; SQ: first quad it stores (-1: none)
-    auto step = [&](auto PAR, auto FIRST, auto ISSUE, auto SQ, int p) {
+    auto step = [&](auto PAR, auto FIRST, auto ISSUE, auto SQ, int p, auto RQ) {
       constexpr int cur = decltype(PAR)::value, nxt = cur ^ 1;
       constexpr bool first = decltype(FIRST)::value;
       constexpr bool do_issue = decltype(ISSUE)::value;
       constexpr int sq = decltype(SQ)::value;
+      constexpr int rq = decltype(RQ)::value;   // first of the eight residual quads this step requests (-1: none)
       // An odd step needs the pair (p+1, p+2) complete.  Its last request went out in step p-2 (or before the
       // item); younger are at least the eight requests of step p-1 and that step's deferred stores (counting
       // only those is the stricter wait); the last four steps have sent nothing.
       if constexpr (cur == 1) {
-        if constexpr (!do_issue) wait_vm<0>();
-        else wait_vm<8 + (sq >= 0 ? SPS : 0)>();
+        if constexpr (do_issue) wait_vm<8 + (sq >= 0 ? SPS : 0)>();
+        else if constexpr (rq < 0) wait_vm<0>();
+        // with residual requests in the last four steps: the second of them still needs the last pair, behind
+        // which only the eight requests of the step before lie; the last step needs nothing new
+        else if constexpr (rq == 8) wait_vm<8>();
       }
       // even step p: A pieces of pair (p+4, p+5); odd step p: B pieces of pair (p+3, p+4)
       const int hpair = cur == 0 ? p + 4 : p + 3;
@@ -248,6 +265,7 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
         constexpr int gst = (2 * WR + 5) % 8;
         if constexpr (gq == 2 * WR || gq == 2 * WR + 1) {
           if constexpr (do_issue) dma(IC<j>{}, cur == 1, gq == 2 * WR ? voff : voff2);
+          else if constexpr (rq >= 0) res_load(IC<rq + 2 * j + (gq - 2 * WR)>{});
         } else if constexpr (gq == gst) {
           if constexpr (sq >= 0 && j < SPS) store_q(pk[sq + j], srd_prev, soff, IC<(sq + j) % 4>{});
         } else {
@@ -281,8 +299,8 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     auto store_steps = [&](auto self, auto P) {
       constexpr int p = decltype(P)::value;
       if constexpr (p < NSS) {
-        if constexpr (p == 0) step(IC<0>{}, T_{}, T_{}, IC<NOW>{}, 0);
-        else step(IC<(p & 1)>{}, F_{}, T_{}, IC<NOW + SPS * p>{}, p);
+        if constexpr (p == 0) step(IC<0>{}, T_{}, T_{}, IC<NOW>{}, 0, IC<-1>{});
+        else step(IC<(p & 1)>{}, F_{}, T_{}, IC<NOW + SPS * p>{}, p, IC<-1>{});
         self(self, IC<p + 1>{});
       }
     };
@@ -290,12 +308,22 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     int p = NSS;
     // steps up to np-5 send (the pairs up to (np-2, np-1)); the last four send nothing
     for (; p < np - 4; p += 2) {
-      step(IC<0>{}, F_{}, T_{}, IC<-1>{}, p);
-      step(IC<1>{}, F_{}, T_{}, IC<-1>{}, p + 1);
+      step(IC<0>{}, F_{}, T_{}, IC<-1>{}, p, IC<-1>{});
+      step(IC<1>{}, F_{}, T_{}, IC<-1>{}, p + 1, IC<-1>{});
     }
-    for (; p < np; p += 2) {
-      step(IC<0>{}, F_{}, F_{}, IC<-1>{}, p);
-      step(IC<1>{}, F_{}, F_{}, IC<-1>{}, p + 1);
+    // the last four steps send no LDS-DMA; with a residual their request gaps carry its 32 quads, which land in
+    // the registers of the packed output (free since the deferred stores of the item before went out)
+    if constexpr (RESID) {
+      rptr = (const char *)(g.R + (m0 + wm * 128) * g.ldc + n0 + wn * 128);
+      step(IC<0>{}, F_{}, F_{}, IC<-1>{}, p, IC<0>{});
+      step(IC<1>{}, F_{}, F_{}, IC<-1>{}, p + 1, IC<8>{});
+      step(IC<0>{}, F_{}, F_{}, IC<-1>{}, p + 2, IC<16>{});
+      step(IC<1>{}, F_{}, F_{}, IC<-1>{}, p + 3, IC<24>{});
+    } else {
+      for (; p < np; p += 2) {
+        step(IC<0>{}, F_{}, F_{}, IC<-1>{}, p, IC<-1>{});
+        step(IC<1>{}, F_{}, F_{}, IC<-1>{}, p + 1, IC<-1>{});
+      }
     }
     // (the asm MFMAs' results: wait states the compiler does not count)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -321,9 +349,11 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
       if (more) wait_vm<32>(); else wait_vm<0>();
       asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
     } else {
+      if constexpr (RESID) { if (more) wait_vm<32>(); else wait_vm<0>(); }
 #pragma unroll
       for (int ni = 0; ni < 8; ++ni) bv[ni] = f4_t{0.f, 0.f, 0.f, 0.f};
     }
+    // (the residual quads are older than the bias requests and the next item's prologue: they have landed)
     // Pack: quad j = (16-row block j / 4, 64-byte group j % 4) = fragments 2t and 2t+1 (t = j % 4) of block
     // mi = j / 4.  A lane holds, per fragment, four consecutive columns of row lane & 15 at column group
     // q = lane >> 4; exchanging 16-lane rows between the packed fragments (odd rows of one with even rows of
@@ -354,7 +384,18 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
         constexpr int j = decltype(J)::value;
         if constexpr (j < 32) {
           constexpr int mi = j / 4, t = j % 4;
-          const f4_t a = rd(acc[2 * t][mi]) + bv[2 * t], b = rd(acc[2 * t + 1][mi]) + bv[2 * t + 1];
+          f4_t a = rd(acc[2 * t][mi]) + bv[2 * t], b = rd(acc[2 * t + 1][mi]) + bv[2 * t + 1];
+          if constexpr (RESID) {
+            // the residual quad has the layout of the packed output; the same exchange of 16-lane rows takes
+            // it back to the accumulators' layout (the exchange is its own inverse)
+            asm volatile("" : "+v"(pk[j]));
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[j][0], pk[j][2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[j][1], pk[j][3], false, false);
+            a[0] += __uint_as_float(s0[0] << 16); a[1] += __uint_as_float(s0[0] & 0xffff0000u);
+            a[2] += __uint_as_float(s1[0] << 16); a[3] += __uint_as_float(s1[0] & 0xffff0000u);
+            b[0] += __uint_as_float(s0[1] << 16); b[1] += __uint_as_float(s0[1] & 0xffff0000u);
+            b[2] += __uint_as_float(s1[1] << 16); b[3] += __uint_as_float(s1[1] & 0xffff0000u);
+          }
           const unsigned a0 = pack_bf16x2(a[0], a[1]), a1 = pack_bf16x2(a[2], a[3]);
           const unsigned b0 = pack_bf16x2(b[0], b[1]), b1 = pack_bf16x2(b[2], b[3]);
           const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
@@ -384,14 +425,15 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
   }
 }
 
+template <bool RESID>
 __global__ __launch_bounds__(256, 1) void gemm4w_k(WArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // one copy of the code per wave: the copies differ in which gap of a step holds what
-  if (wave == 0) gemm4w_body<0>(g, smem);
-  else if (wave == 1) gemm4w_body<1>(g, smem);
-  else if (wave == 2) gemm4w_body<2>(g, smem);
-  else gemm4w_body<3>(g, smem);
+  if (wave == 0) gemm4w_body<0, RESID>(g, smem);
+  else if (wave == 1) gemm4w_body<1, RESID>(g, smem);
+  else if (wave == 2) gemm4w_body<2, RESID>(g, smem);
+  else gemm4w_body<3, RESID>(g, smem);
 }
 
 int num_cus4() {
@@ -413,15 +455,17 @@ bool ldm_gemm_4w_enabled() {
   return on;
 }
 
-// C[M, N] (bf16) = A[M, K] * B[N, K]^T (+ bias[N]).  LDM_E_SHAPE / LDM_E_ALIGN for what the kernel does not
-// take (the caller then runs the eight-wave kernel).  dyn_m (nullable): device-side row count <= M; A and C
-// must hold all M rows.
+// C[M, N] (bf16) = A[M, K] * B[N, K]^T (+ bias[N]) (+ R[M, N], bf16, row stride ldc).  LDM_E_SHAPE /
+// LDM_E_ALIGN for what the kernel does not take (the caller then runs the eight-wave kernel).  dyn_m
+// (nullable): device-side row count <= M; A must hold all M rows.
 int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb,
-                         void *C, int64_t ldc, const float *bias, const int *dyn_m, hipStream_t s) {
+                         void *C, int64_t ldc, const float *bias, const void *R, const int *dyn_m, hipStream_t s) {
   if (M < 256 || M % 256 || N < 256 || N % 256) return LDM_E_SHAPE;
   if (K % 64 || K < (int64_t)(NSS + 4) * KH) return LDM_E_SHAPE;
   if (lda % 8 || ldb % 8 || ldc % 8 || lda < K || ldb < K || ldc < N) return LDM_E_ALIGN;
-  if (!aligned_to(A, 16) || !aligned_to(B, 16) || !aligned_to(C, 16) || (bias && !aligned_to(bias, 16))) return LDM_E_ALIGN;
+  if (!aligned_to(A, 16) || !aligned_to(B, 16) || !aligned_to(C, 16) || (bias && !aligned_to(bias, 16)) ||
+      (R && !aligned_to(R, 16)))
+    return LDM_E_ALIGN;
   // 32-bit lane offsets: 16 rows of an operand plus the k offset, 128 rows of C
   if (lda >= (1 << 26) || ldb >= (1 << 26) || ldc >= (1 << 23)) return LDM_E_SHAPE;
   const int64_t tm = M / 256, tn = N / 256;
@@ -430,6 +474,7 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
   g.M = M; g.N = N; g.K = K;
   g.A = (const bf16_t *)A; g.lda = lda; g.B = (const bf16_t *)B; g.ldb = ldb; g.C = (bf16_t *)C; g.ldc = ldc;
   g.bias = bias;
+  g.R = (const bf16_t *)R;
   g.dyn_m = dyn_m;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn;
   {
@@ -444,12 +489,14 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
   static std::atomic<uint64_t> attr_done{0};
   uint64_t dev_bit;
   if (ldm_attr_pending(attr_done, &dev_bit)) {
-    (void)hipFuncSetAttribute((const void *)gemm4w_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)gemm4w_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)gemm4w_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   const int64_t items = tm * tn;
   const int64_t nwg = items < num_cus4() ? items : num_cus4();   // persistent: one workgroup per CU
-  hipLaunchKernelGGL(gemm4w_k, dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
+  if (R) hipLaunchKernelGGL(gemm4w_k<true>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
+  else hipLaunchKernelGGL(gemm4w_k<false>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }

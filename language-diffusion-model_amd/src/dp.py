@@ -140,6 +140,9 @@ class GradBucketDataParallel(nn.Module):
                 ident[0] = buf.raw
         dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group else 0, group=group)
         stream = torch.cuda.Stream(device=device)
+        # two communicators (torch.distributed's and this one) never have collectives in flight at the same
+        # time: the device is idle before this one's first collective, and again before torch's next one
+        torch.cuda.synchronize(device)
         try:
             if ident[0] is None:
                 raise RuntimeError("rank 0 could not create a communicator id: " + lib.ldm_comm_last_error().decode())
@@ -154,6 +157,7 @@ class GradBucketDataParallel(nn.Module):
                     raise RuntimeError("probe all-reduce returned a wrong sum")
         except Exception as e:       # noqa: BLE001 -- any failure means: use torch.distributed
             ok, why = 0, str(e)
+        torch.cuda.synchronize(device)
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 1:

@@ -613,12 +613,13 @@ def test_gemm_persistent_many_tiles(dev, tb, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(512, 512, 320), (256, 256, 2304), (2048, 768, 1024), (8192, 2304, 768),
                                    (66 * 256, 512, 384)])
-@pytest.mark.parametrize("bias", [False, True])
-def test_gemm_four_wave(dev, M, N, K, bias):
+@pytest.mark.parametrize("bias,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_gemm_four_wave(dev, M, N, K, bias, res):
     """Shapes the four-wave kernel takes (K-contiguous operands, full 256 x 256 tiles, K % 64 == 0, K >= 320):
     one item per workgroup, several items per workgroup (deferred stores between items, the last item's flush),
-    more tiles than CUs with an uneven last round, padded leading dimensions.  Checked element by element
-    (a wrong tile or a lost store must not hide in a norm) against the fp64 product of the bf16 inputs."""
+    more tiles than CUs with an uneven last round, padded leading dimensions, bias and a bf16 residual with the
+    output's row stride (added before the rounding).  Checked element by element (a wrong tile or a lost store
+    must not hide in a norm) against the fp64 product of the bf16 inputs."""
     from src import _native as Nn
     torch.manual_seed(11)
     lda, ldb, ldc = K + 64, K + 8, N + 24
@@ -626,11 +627,14 @@ def test_gemm_four_wave(dev, M, N, K, bias):
     b = torch.randn(N, ldb, device=dev).bfloat16()
     bv = torch.randn(N, device=dev) if bias else None
     c = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device=dev)
+    r = (torch.randn(M, ldc, device=dev) * 3).bfloat16() if res else None
     Nn.check(Nn.lib().ldm_gemm(Nn.BF16, Nn.BF16, 0, 1, M, N, K, 1.0, a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(),
-                               ldc, Nn.ptr(bv), None, 0, Nn.stream()), "ldm_gemm")
+                               ldc, Nn.ptr(bv), Nn.ptr(r), ldc if res else 0, Nn.stream()), "ldm_gemm")
     ref = a[:, :K].double() @ b[:, :K].double().t()
     if bias:
         ref = ref + bv.double()
+    if res:
+        ref = ref + r[:, :N].double()
     got = c[:, :N].double()
     err = (got - ref).abs()
     bound = ref.abs() * 2.0 ** -8 + 1e-2      # bf16 rounding of the result (2^-9 relative) with headroom
