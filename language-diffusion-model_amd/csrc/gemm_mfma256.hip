@@ -1370,6 +1370,9 @@ int ldm_gemm_mfma256_bf16_acc_dynk(int transA, int transB, int64_t M, int64_t N,
 int ldm_gemm_mfma256_bf16_acc(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
                               int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, float *rowsum,
                               hipStream_t s) {
+  // (A four-wave form of this product -- transposing reads, 32 per step and wave -- was built and measured:
+  // equal to this kernel at the q/k/v and gate/up shapes, 20-40 % slower at the 768-wide ones and at the
+  // shapes of the larger models; scripts/micro/gemm4w_st_probe.hip keeps it.)
   MArgs g;
   const int rc = fill(g, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0);
   if (rc) return rc;

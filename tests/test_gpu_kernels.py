@@ -283,6 +283,40 @@ def test_gemm_acc_rowsum(dev, ta, tb, M, N, K):
     assert rel_err(r, r0.double() + A.sum(dim=1)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (256, 512, 576), (768, 2304, 8192), (2304, 768, 16384),
+                                   (2048, 768, 65536), (1024, 768, 3200)])
+@pytest.mark.parametrize("rowsum", [False, True])
+def test_gemm_acc_elementwise(dev, M, N, K, rowsum):
+    """The weight-gradient product (A [K, M], B [K, N], fp32 accumulate) on full 256 x 256 tiles: one work item
+    and many, uneven splits of the reduction, padded leading dimensions, row sums.  Every element is checked (a
+    misplaced fragment must not hide in a norm) against the fp64 product of the bf16 inputs."""
+    from src import _native as Nn
+    torch.manual_seed(12)
+    lda, ldb, ldc = M + 64, N + 8, N + 12
+    a = torch.randn(K, lda, device=dev).bfloat16()
+    b = torch.randn(K, ldb, device=dev).bfloat16()
+    c0 = torch.randn(M, ldc, device=dev)
+    r0 = torch.randn(M, device=dev)
+    c, r = c0.clone(), r0.clone()
+    if rowsum:
+        Nn.check(Nn.lib().ldm_gemm_acc_rowsum(1, 0, M, N, K, 1.0, a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
+                                              r.data_ptr(), Nn.stream()), "ldm_gemm_acc_rowsum")
+    else:
+        Nn.check(Nn.lib().ldm_gemm_acc(1, 1, 0, M, N, K, 1.0, a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
+                                       Nn.stream()), "ldm_gemm_acc")
+    A, Bm = a[:, :M].double().t(), b[:, :N].double()
+    ref = c0[:, :N].double() + A @ Bm
+    err = (c[:, :N].double() - ref).abs()
+    bound = 1e-4 * math.sqrt(K) + 1e-5 * ref.abs()      # fp32 accumulation of K products of O(1) terms
+    assert bool((err <= bound).all()), f"max excess {float((err - bound).max())}"
+    assert torch.equal(c[:, N:], c0[:, N:])               # nothing written beyond the N columns
+    if rowsum:
+        rr = r0.double() + A.sum(dim=1)
+        assert bool(((r.double() - rr).abs() <= 1e-4 * math.sqrt(K) + 1e-5 * rr.abs()).all())
+    else:
+        assert torch.equal(r, r0)
+
+
 def test_gemm_bf16_fallback_shapes(dev):
     """Shapes the MFMA kernel does not take (K % 64 != 0) run on the FMA kernel."""
     torch.manual_seed(2)
