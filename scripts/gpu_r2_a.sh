@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 check: GPU tests , smoke, bench with and without launch events.
+# Check: GPU tests , smoke, bench with and without launch events.
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 1000 python -u -m pytest tests -m gpu -q --tb=short -s --timeout 400 --timeout-method thread -p no:cacheprovider > gpurun_out/tests.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profiles of the bench command at its default shape (per-GPU batch 512, seq 512, bf16):
+# Profiles (named r3_*) of the bench command at its default shape (per-GPU batch 512, seq 512, bf16):
 #   1. rocprofv3 --kernel-trace --stats                      -> gpurun_out/r3_prof/kernel_stats.csv
 #   2. one --pmc pass each for FETCH_SIZE and WRITE_SIZE       -> gpurun_out/r3_prof/traffic.json  (per kernel, per launch)
 #   3. one --pmc pass for MFMA-busy and wait counters          -> gpurun_out/r3_prof/mfma_util.json
