@@ -199,7 +199,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
-    if world > 1:
+    # (LDM_DP_FORCE=1 under a launcher: one rank with the process group and the bucket machinery on -- the
+    # rehearsal of the multi-rank path on a one-GPU box)
+    if world > 1 or (os.environ.get("LDM_DP_FORCE") == "1" and "MASTER_ADDR" in os.environ):
         backend = os.environ.get("LDM_DP_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -371,7 +373,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.seq)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
