@@ -375,6 +375,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
+        if isinstance(model, GradBucketDataParallel):
+            model.close()
         dist.destroy_process_group()
 
 

@@ -260,6 +260,14 @@ class GradBucketDataParallel(nn.Module):
             b.work = None
             b.ready.clear()
 
+    def close(self):
+        """Release this wrapper's RCCL communicator (every rank calls it, before the process group goes)."""
+        comm, self._comm = self._comm, None
+        if comm is not None:
+            from . import _native as N
+            torch.cuda.synchronize()
+            N.lib().ldm_comm_destroy(comm)
+
     def finish_grad_sync(self):
         """Explicit form of the end-of-backward callback (idempotent)."""
         if self._callback_queued:

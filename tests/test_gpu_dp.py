@@ -319,6 +319,8 @@ def _native_dp_worker(port, q):
         torch.manual_seed(3)
         losses = [trainer.loss_value(trainer._step(batch)) for _ in range(3)]
         res[str(wire)] = (losses, {n: p.detach().cpu().numpy() for n, p in model.module.named_parameters()})
+        model.close()
+        assert model._comm is None
     q.put(res)
     dist.barrier()
     dist.destroy_process_group()
