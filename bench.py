@@ -144,9 +144,10 @@ def summarize_events(events, steps):
 
 def committed_traffic(cfg_name, dtype, batch, seq):
     """Memory-side bytes per launch of the GEMM class from the committed PMC passes
-    (profiles/r2_gemm_traffic.json, made by scripts/gpu_pmc_bench.sh at the bench shape); None if this
-    run's shape is not the one that was profiled."""
-    path = os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")
+    (profiles/r3_gemm_traffic.json, made by scripts/gpu_r3_profile.sh at the bench shape: the counters need
+    passes of their own under rocprofv3, so the figure is read, not measured in this run); None if this run's
+    shape is not the one that was profiled."""
+    path = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
     if not os.path.exists(path):
         return None
     tj = json.load(open(path))

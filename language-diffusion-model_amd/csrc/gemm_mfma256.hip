@@ -1,6 +1,6 @@
 // Large-tile bf16 MFMA GEMM for gfx950: 256 x BN output tile (BN = 256 or 128), 8 waves,
 // one workgroup per CU, operands streamed global -> LDS by 16-byte LDS-DMA through a ring
-// of FOUR 32-deep half-tiles so that up to three half-tiles stay in flight across the
+// of FIVE 32-deep half-tiles (NSLOT) so that up to four half-tiles stay in flight across the
 // per-phase barrier (counted vmcnt, raw s_barrier).
 //
 // Why the big tile: at 128x128 a workgroup streams 32 KiB from L2 per 2.1 MFLOP

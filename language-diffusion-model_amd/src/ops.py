@@ -205,10 +205,11 @@ KERNEL_EVENTS: dict | None = None
 
 
 class _Timed:
-    __slots__ = ("lst", "e0", "work", "count")
+    __slots__ = ("lst", "e0", "work", "count", "declined")
 
     def __init__(self, tag, work, count=None):
         self.lst = None
+        self.declined = False        # set inside the block when the kernel declined the problem: no record
         if KERNEL_EVENTS is not None:
             self.lst = KERNEL_EVENTS.setdefault(tag, [])
             self.work, self.count = work, count
@@ -220,7 +221,7 @@ class _Timed:
         return self
 
     def __exit__(self, *exc):
-        if self.lst is not None:
+        if self.lst is not None and not self.declined:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             self.lst.append((self.e0, e1, self.work, self.count))
@@ -265,9 +266,10 @@ def _project_residual(dt, T, n_pad, k, a, lda, w, y, b, res, drop):
     p, seed = drop
     rc = -3
     if FUSED_RESIDUAL_DROPOUT and dt == torch.bfloat16 and res is not None:
-        with _Timed("gemm.fwd", 2.0 * T * n_pad * k):
+        with _Timed("gemm.fwd", 2.0 * T * n_pad * k) as tm:
             rc = N.lib().ldm_gemm_dropout_residual(T, n_pad, k, a.data_ptr(), lda, w.data_ptr(), k, N.ptr(b),
                                                    res.data_ptr(), ldr, y.data_ptr(), n_pad, float(p), int(seed), N.stream())
+            tm.declined = rc in (-2, -3)
         if rc not in (-2, -3):
             N.check(rc, "ldm_gemm_dropout_residual")
     if rc in (-2, -3):
@@ -300,9 +302,10 @@ def _weight_bias_grads(pack, g, x_in, ld_x, T, k, dev, dt):
     dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
     rc = -2
     if dt == torch.bfloat16 and FUSED_BIAS_GRAD:
-        with _Timed("gemm.dw", 2.0 * n_pad * k * T):
+        with _Timed("gemm.dw", 2.0 * n_pad * k * T) as tm:
             rc = N.lib().ldm_gemm_acc_rowsum(1, 0, n_pad, k, T, 1.0, g.data_ptr(), n_pad, x_in.data_ptr(), ld_x,
                                              dw.data_ptr(), k, db.data_ptr(), N.stream())
+            tm.declined = rc in (-2, -3)
         if rc not in (-2, -3):
             N.check(rc, "ldm_gemm_acc_rowsum")
     if rc in (-2, -3):
@@ -361,11 +364,12 @@ class _PackedLinear(torch.autograd.Function):
         rc = -3
         if (rope is not None and FUSED_QKV_ROPE and dt == torch.bfloat16 and res is None and pack.n_pad == pack.n
                 and len(pack.n_each) == 3 and pack.n_each[0] == pack.n_each[1] == pack.n_each[2]):
-            with _Timed("gemm.fwd", 2.0 * T * pack.n_pad * k):
+            with _Timed("gemm.fwd", 2.0 * T * pack.n_pad * k) as tm:
                 rc = N.lib().ldm_gemm_qkv_rope(T, pack.n_each[0], k, rope.hd, rope.seq, x2.data_ptr(), x2.stride(0),
                                                w.data_ptr(), k, N.ptr(b), rope.cos.data_ptr(), rope.sin.data_ptr(),
                                                rope.step.data_ptr(), float(rope.q_scale), y.data_ptr(), pack.n_pad,
                                                N.stream())
+                tm.declined = rc in (-2, -3)
             if rc not in (-2, -3):
                 N.check(rc, "ldm_gemm_qkv_rope")
                 rope.applied = True
@@ -437,17 +441,19 @@ def _compact_input_grad(pack, gc, rows, count, T, k, w):
     wt = pack.get_t() if (DX_TRANSPOSED_WEIGHTS and rows_alloc % 256 == 0 and k % 256 == 0 and n_pad % 64 == 0) else None
     if wt is not None:
         dxc = torch.empty(rows_alloc, k, dtype=torch.bfloat16, device=dev)
-        with _Timed("gemm.dx", 2.0 * k * n_pad, count):
+        with _Timed("gemm.dx", 2.0 * k * n_pad, count) as tm:
             rc = lib.ldm_gemm_rows_dyn(N.BF16, 1, rows_alloc, k, n_pad, gc.data_ptr(), n_pad, wt.data_ptr(), n_pad,
                                        dxc.data_ptr(), k, None, count.data_ptr(), None, st)
+            tm.declined = rc in (-2, -3)
         if rc not in (-2, -3):
             N.check(rc, "ldm_gemm_rows_dyn")
             N.check(lib.ldm_scatter_rows(dxc.data_ptr(), N.BF16, k, rows.data_ptr(), count.data_ptr(), rows_alloc, T, k,
                                          dx.data_ptr(), k, st), "ldm_scatter_rows")
             return dx
-    with _Timed("gemm.dx", 2.0 * k * n_pad, count):
+    with _Timed("gemm.dx", 2.0 * k * n_pad, count) as tm:
         rc = lib.ldm_gemm_rows_dyn(N.BF16, 0, T, k, n_pad, gc.data_ptr(), n_pad, w.data_ptr(), k, dx.data_ptr(), k,
                                    None, count.data_ptr(), rows.data_ptr(), st)
+        tm.declined = rc in (-2, -3)
     if rc in (-2, -3):
         return None
     N.check(rc, "ldm_gemm_rows_dyn")
@@ -473,9 +479,10 @@ def _backward_compact(ctx, x2, w, dlc, rows, count):
                                 xc.data_ptr(), st), "ldm_gather_rows")
     dwb = ZERO_POOL.take(n_pad * k + n_pad, dev)
     dw, db = dwb[:n_pad * k].view(n_pad, k), dwb[n_pad * k:]
-    with _Timed("gemm.dw", 2.0 * n_pad * k, count):
+    with _Timed("gemm.dw", 2.0 * n_pad * k, count) as tm:
         rc = lib.ldm_gemm_acc_kdyn(1, 0, n_pad, k, Tp, dlc.data_ptr(), n_pad, xc.data_ptr(), k, dw.data_ptr(), k,
                                    count.data_ptr(), db.data_ptr() if FUSED_BIAS_GRAD else None, st)
+        tm.declined = rc in (-2, -3)
     if rc in (-2, -3):
         return None
     N.check(rc, "ldm_gemm_acc_kdyn")
@@ -692,9 +699,10 @@ class _SwiGLUUp(torch.autograd.Function):
         h = torch.empty(T, F, dtype=dt, device=x2.device)
         rc = -3
         if FUSED_SWIGLU_UP and dt == torch.bfloat16 and pack.n_pad == pack.n:
-            with _Timed("gemm.fwd", 2.0 * T * pack.n_pad * k):
+            with _Timed("gemm.fwd", 2.0 * T * pack.n_pad * k) as tm:
                 rc = N.lib().ldm_gemm_swiglu_fwd(T, F, k, x2.data_ptr(), x2.stride(0), w.data_ptr(), k, N.ptr(b),
                                                  y.data_ptr(), pack.n_pad, h.data_ptr(), F, N.stream())
+                tm.declined = rc in (-2, -3)
             if rc not in (-2, -3):
                 N.check(rc, "ldm_gemm_swiglu_fwd")
         if rc in (-2, -3):
@@ -798,9 +806,10 @@ class _SwiGLUDown(torch.autograd.Function):
             dag = torch.empty_like(ag2)
             rc = -3
             if dt == torch.bfloat16 and FUSED_SWIGLU_DOWN:
-                with _Timed("gemm.dx", 2.0 * T * F * n_pad):
+                with _Timed("gemm.dx", 2.0 * T * F * n_pad) as tm:
                     rc = lib.ldm_gemm_swiglu_bwd(T, F, n_pad, g.data_ptr(), n_pad, w.data_ptr(), F, ag2.data_ptr(), 2 * F,
                                                  dag.data_ptr(), 2 * F, N.stream())
+                    tm.declined = rc in (-2, -3)
                 if rc not in (-2, -3):
                     N.check(rc, "ldm_gemm_swiglu_bwd")
             if rc in (-2, -3):
@@ -947,10 +956,11 @@ class _RopeAttention(torch.autograd.Function):
         # attention backward with the rotary backward fused into its stores where the kernel has it
         rc = -3
         if FUSED_UNROPE and dt == torch.bfloat16:
-            with _Timed("attn.bwd", 10.0 * B * H * S * S * hd):
+            with _Timed("attn.bwd", 10.0 * B * H * S * S * hd) as tm:
                 rc = lib.ldm_attn_bwd_unrope(code, q2.data_ptr(), 3 * D, N.ptr(ctx.key_valid), B, H, S, hd, o.data_ptr(),
                                              g.data_ptr(), D, saved.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
                                              cos.data_ptr(), sin.data_ptr(), 1.0 / math.sqrt(hd), N.stream())
+                tm.declined = rc in (-2, -3)
             if rc not in (-2, -3):
                 N.check(rc, "ldm_attn_bwd_unrope")
         if rc in (-2, -3):
