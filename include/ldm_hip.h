@@ -80,6 +80,17 @@ int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd, const void
                     const void *dres, int64_t T, int64_t d, int dtype, void *dx, float *dw,
                     float *dw_partial, void *stream);
 
+/* ldm_rmsnorm_bwd with a second output dx_drop = keep * dx / (1 - p), where keep is the mask that
+ * ldm_dropout_add(y, res, out, T, d, dtype, p, seed) applied when it formed the norm's input x = out
+ * (src/transformer.py:352,361 feed `src + self.dropout(...)` to the next norm): dx is the gradient of
+ * that sum, dx_drop the gradient of the dropout's operand, so the projection behind the dropout needs no
+ * masking pass of its own.  dx_drop is formed from dx as stored (rounded to dtype).  d % 8 == 0 and
+ * d <= 4096 and 16-byte-aligned rows, else LDM_E_SHAPE / LDM_E_ALIGN (use the two calls). */
+int ldm_rmsnorm_bwd_dropgrad(const void *x, const float *w, const float *rstd, const void *dy,
+                             const void *dres, int64_t T, int64_t d, int dtype, void *dx,
+                             void *dx_drop, float p, uint64_t seed, float *dw, float *dw_partial,
+                             void *stream);
+
 /* ldm_rmsnorm_bwd for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): the same kernels and results, but the dw partials live in a
  * fixed 8 MiB device array inside the library instead of a caller-provided workspace, so the call

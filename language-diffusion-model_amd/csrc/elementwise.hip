@@ -207,10 +207,15 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd8_k(const T *x, const float *w
   }
 }
 
-template <typename T, int NV, bool RES>
+// dx_drop (nullable): a second output, keep * dx / (1 - p) with the residual-dropout mask of the projection
+// whose output this norm read (row = token, column = feature; the mask of ldm_dropout_add): the gradient that
+// projection's backward needs, written here instead of by a masking pass of its own over dx.
+struct RmsDrop { void *dx_drop; unsigned thresh, seed_lo, seed_hi; float inv; };
+
+template <typename T, int NV, bool RES, bool DROP>
 __global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w, const float *rstd, const T *dy,
                                                       const T *dres, int64_t rows, int d, T *dx,
-                                                      float *dw_partial) {
+                                                      float *dw_partial, RmsDrop dr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][d]
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -265,6 +270,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w
           if (RES) o[j] += rv[i].get(j);
         }
         Raw8<T>::store_nt(dx + r * d + vi * 8, o);
+        if constexpr (DROP) {
+          const unsigned rk = ldm_drop_row(ldm_drop_bh(dr.seed_lo, 0xffffffffu), dr.seed_hi, (unsigned)r);
+          float o2[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            // the masked copy is formed from the STORED value of dx (rounded to T), as a pass over dx would
+            float v = o[j];
+            if constexpr (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));
+            o2[j] = ldm_drop_keep(rk, (unsigned)(vi * 8 + j), dr.thresh) ? v * dr.inv : 0.f;
+          }
+          Raw8<T>::store_nt((T *)dr.dx_drop + r * d + vi * 8, o2);
+        }
       }
     }
   }
@@ -830,20 +847,23 @@ extern "C" int64_t ldm_rmsnorm_bwd_ws_floats(int64_t T, int64_t d) {
 template <typename T>
 static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, const void *dy,
                               const void *dres, int64_t rows, int64_t d, void *dx, float *dw,
-                              float *dw_partial, hipStream_t s, int64_t max_blocks = kRmsBwdBlocks) {
+                              float *dw_partial, hipStream_t s, int64_t max_blocks = kRmsBwdBlocks,
+                              RmsDrop dr = RmsDrop{nullptr, 0u, 0u, 0u, 1.0f}) {
   int64_t blocks = ceil_div(rows, 4);
   if (blocks > max_blocks) blocks = max_blocks;
   const unsigned grid = (unsigned)blocks;
   const size_t lds = (size_t)4 * d * sizeof(float);
   if (d % 8 == 0 && rms_nv8(d) <= 8) {
+#define RMS_B8_(NV, RES, DROP)                                                                                    \
+  hipLaunchKernelGGL((rmsnorm_bwd8_k<T, NV, RES, DROP>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,    \
+                     (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial, dr)
 #define RMS_B8(NV)                                                                                                \
   do {                                                                                                            \
-    if (dres)                                                                                                     \
-      hipLaunchKernelGGL((rmsnorm_bwd8_k<T, NV, true>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,      \
-                         (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial);                      \
-    else                                                                                                          \
-      hipLaunchKernelGGL((rmsnorm_bwd8_k<T, NV, false>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,     \
-                         (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial);                      \
+    if (dr.dx_drop) {                                                                                             \
+      if (dres) RMS_B8_(NV, true, true); else RMS_B8_(NV, false, true);                                           \
+    } else {                                                                                                      \
+      if (dres) RMS_B8_(NV, true, false); else RMS_B8_(NV, false, false);                                         \
+    }                                                                                                             \
   } while (0)
     switch (rms_nv8(d)) {
       case 1: RMS_B8(1); break;
@@ -852,12 +872,14 @@ static int rmsnorm_bwd_launch(const void *x, const float *w, const float *rstd, 
       default: RMS_B8(8); break;
     }
 #undef RMS_B8
+#undef RMS_B8_
     LDM_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(1024), 0, s, dw_partial,
                        (int64_t)grid, d, dw);
     LDM_CHECK_LAUNCH();
     return LDM_OK;
   }
+  if (dr.dx_drop) return LDM_E_SHAPE;   // the second output exists in the 16-byte-vector kernels only
 #define RMS_B(NV)                                                                                      \
   hipLaunchKernelGGL((rmsnorm_bwd_k<T, NV>), dim3(grid), dim3(256), lds, s, (const T *)x, w, rstd,      \
                      (const T *)dy, (const T *)dres, rows, (int)d, (T *)dx, dw_partial)
@@ -894,6 +916,32 @@ extern "C" int ldm_rmsnorm_bwd(const void *x, const float *w, const float *rstd,
     return LDM_E_ALIGN;
   if (dtype == LDM_F32) return rmsnorm_bwd_launch<float>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s);
   if (dtype == LDM_BF16) return rmsnorm_bwd_launch<bf16_t>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s);
+  return LDM_E_DTYPE;
+}
+
+// ldm_rmsnorm_bwd with a second output dx_drop = keep * dx / (1 - p), the mask that
+// ldm_dropout_add(y, res, out, T, d, dtype, p, seed) applied to the [T, d] tensor this norm read.
+extern "C" int ldm_rmsnorm_bwd_dropgrad(const void *x, const float *w, const float *rstd, const void *dy,
+                                        const void *dres, int64_t T, int64_t d, int dtype, void *dx, void *dx_drop,
+                                        float p, uint64_t seed, float *dw, float *dw_partial, void *stream) {
+  if (T < 0 || d <= 0 || !(p >= 0.0f) || !(p < 1.0f)) return LDM_E_BADARG;
+  if (!dw) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 0) return (int)hipMemsetAsync(dw, 0, d * sizeof(float), s);
+  if (!x || !w || !rstd || !dy || !dx || !dx_drop || !dw_partial) return LDM_E_BADARG;
+  if (d % 8 || d > 4096) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(dy, 16) || !aligned_to(dx, 16) || !aligned_to(dx_drop, 16) || !aligned_to(w, 16) ||
+      (dres && !aligned_to(dres, 16)))
+    return LDM_E_ALIGN;
+  // threshold and scale exactly as ldm_dropout_add derives them
+  const double t = (double)p * 4294967296.0;
+  RmsDrop dr;
+  dr.dx_drop = dx_drop;
+  dr.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  dr.inv = (float)(4294967296.0 / (4294967296.0 - (double)dr.thresh));
+  dr.seed_lo = (unsigned)seed; dr.seed_hi = (unsigned)(seed >> 32);
+  if (dtype == LDM_F32) return rmsnorm_bwd_launch<float>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s, kRmsBwdBlocks, dr);
+  if (dtype == LDM_BF16) return rmsnorm_bwd_launch<bf16_t>(x, w, rstd, dy, dres, T, d, dx, dw, dw_partial, s, kRmsBwdBlocks, dr);
   return LDM_E_DTYPE;
 }
 

@@ -282,10 +282,55 @@ def _project_residual(dt, T, n_pad, k, a, lda, w, y, b, res, drop):
                                         int(seed), N.stream()), "ldm_dropout_add")
 
 
-def _drop_grad(g, drop):
-    """Gradient w.r.t. the projection output under the residual dropout: keep * g / (1 - p), same mask."""
+FUSED_DROP_GRAD = os.environ.get("LDM_FUSED_DROP_GRAD", "1") != "0"   # masked gradient written by the norm's backward
+
+
+class _Drop:
+    """One residual dropout: (p, seed), plus the hand-off of its backward.  The tensor res + dropout(y) is
+    normally read by exactly one RMSNorm; that norm's backward kernel produces the total gradient dx of the
+    tensor and can write keep * dx / (1 - p) beside it (ldm_rmsnorm_bwd_dropgrad), which is the gradient
+    the projection's backward needs.  The norm leaves both here; the projection takes the masked copy only
+    if the gradient autograd hands it IS that dx (same storage, unmodified), and masks it itself otherwise.
+    Holding ``dx`` keeps its address from being reused and keeps autograd from accumulating into it."""
+    __slots__ = ("p", "seed", "dx", "dx_drop", "ver")
+
+    def __init__(self, p: float, seed: int):
+        self.p, self.seed = p, seed
+        self.dx = self.dx_drop = self.ver = None
+
+    def __iter__(self):
+        return iter((self.p, self.seed))
+
+    def take(self, gy, T: int, n: int):
+        dx, dxd, ver = self.dx, self.dx_drop, self.ver
+        self.dx = self.dx_drop = self.ver = None
+        if (dx is not None and gy.data_ptr() == dx.data_ptr() and gy.dtype == dx.dtype and gy.is_contiguous()
+                and gy.numel() == dx.numel() == T * n and dx._version == ver):
+            return dxd.view(T, n)
+        return None
+
+
+def _new_drop(residual, residual_dropout: float):
+    if residual is None or not residual_dropout > 0.0:
+        return None
+    return _Drop(float(residual_dropout), _draw_seed())
+
+
+def _tag_drop(out, drop):
+    if drop is not None and FUSED_DROP_GRAD:
+        out._ldm_drop = drop     # read by the RMSNorm that is handed THIS tensor object
+    return out
+
+
+def _drop_grad(g, drop, gy=None):
+    """Gradient w.r.t. the projection output under the residual dropout: keep * g / (1 - p), same mask.
+    ``gy``: the gradient as autograd delivered it (see _Drop)."""
     if drop is None:
         return g
+    if gy is not None:
+        handed = drop.take(gy, g.shape[0], g.shape[1])
+        if handed is not None:
+            return handed
     p, seed = drop
     gc_ = g if g.is_contiguous() else g.contiguous()
     out = torch.empty_like(gc_)
@@ -418,7 +463,7 @@ class _PackedLinear(torch.autograd.Function):
         else:
             g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
             g[:, :n].copy_(gy)
-        g = _drop_grad(g, ctx.drop)
+        g = _drop_grad(g, ctx.drop, gy)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _input_grad(pack, dt, T, k, n_pad, g, w)
@@ -509,9 +554,10 @@ def packed_linear(x: Tensor, pack: PackedWeights, residual: Tensor | None = None
     shape = x.shape
     x2 = _rows2d(x)
     link = _HeadLink() if pack.compact_rows else None
-    drop = (float(residual_dropout), _draw_seed()) if (residual is not None and residual_dropout > 0.0) else None
+    drop = _new_drop(residual, residual_dropout)
     y = _PackedLinear.apply(x2, residual, pack, link, rope, drop, *pack.weights, *pack.biases)
     out = y.reshape(*shape[:-1], pack.n) if y.is_contiguous() else y.view(*shape[:-1], pack.n)
+    _tag_drop(out, drop)
     if link is not None:
         out._ldm_head_link = link    # read by masked_ce when THIS tensor object is handed to the loss
     return out
@@ -552,9 +598,41 @@ def embedding(ids: Tensor, table: Tensor, out_dtype: torch.dtype, hot_id: int = 
 
 
 # ----------------------------------------------------------------------------
+def _rmsnorm_backward(xc, w, rstd, g, r, drop):
+    """dx (+ r), dw of the norm; with ``drop`` (a _Drop) also the masked copy of dx, left in ``drop``."""
+    d = xc.shape[-1]
+    T = xc.numel() // d
+    es = xc.element_size()
+    lib = N.lib()
+    dx = torch.empty_like(xc)
+    dw = torch.empty(d, dtype=torch.float32, device=xc.device)
+    ws = torch.empty(lib.ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
+    nbuf = 4.0 if r is not None else 3.0
+    if drop is not None and FUSED_DROP_GRAD and T > 0:
+        dxd = torch.empty_like(xc)
+        with _Timed("rmsnorm.bwd", (nbuf + 1.0) * T * d * es) as tm:
+            rc = lib.ldm_rmsnorm_bwd_dropgrad(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
+                                              N.dtype_code(xc.dtype), dx.data_ptr(), dxd.data_ptr(), float(drop.p),
+                                              int(drop.seed), dw.data_ptr(), ws.data_ptr(), N.stream())
+            tm.declined = rc in (-2, -3)
+        if rc not in (-2, -3):
+            N.check(rc, "ldm_rmsnorm_bwd_dropgrad")
+            drop.dx, drop.dx_drop, drop.ver = dx, dxd, dx._version
+            return dx, dw
+    with _Timed("rmsnorm.bwd", nbuf * T * d * es):
+        N.check(lib.ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
+                                    N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), N.stream()),
+                "ldm_rmsnorm_bwd")
+    return dx, dw
+
+
+def _input_drop(x):
+    return getattr(x, "_ldm_drop", None) if torch.is_grad_enabled() else None
+
+
 class _RMSNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, eps):
+    def forward(ctx, x, weight, eps, drop=None):
         N.require_device(x, weight)
         xc = x.contiguous()
         d = xc.shape[-1]
@@ -566,28 +644,21 @@ class _RMSNorm(torch.autograd.Function):
             N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
                                             y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
         ctx.save_for_backward(xc, w, rstd)
+        ctx.drop = drop if xc.data_ptr() == x.data_ptr() else None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xc, w, rstd = ctx.saved_tensors
-        d = xc.shape[-1]
-        T = xc.numel() // d
         g = gy.contiguous()
         if g.dtype != xc.dtype:
             g = g.to(xc.dtype)
-        dx = torch.empty_like(xc)
-        dw = torch.empty(d, dtype=torch.float32, device=xc.device)
-        ws = torch.empty(N.lib().ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
-        with _Timed("rmsnorm.bwd", 3.0 * T * d * xc.element_size()):
-            N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), None, T, d,
-                                            N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                            N.stream()), "ldm_rmsnorm_bwd")
-        return dx, dw, None
+        dx, dw = _rmsnorm_backward(xc, w, rstd, g, None, ctx.drop)
+        return dx, dw, None, None
 
 
 def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
-    return _RMSNorm.apply(x, weight, eps)
+    return _RMSNorm.apply(x, weight, eps, _input_drop(x))
 
 
 class _RMSNormRes(torch.autograd.Function):
@@ -596,7 +667,7 @@ class _RMSNormRes(torch.autograd.Function):
     kernel instead of by a separate elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, eps):
+    def forward(ctx, x, weight, eps, drop=None):
         N.require_device(x, weight)
         xc = x.contiguous()
         d = xc.shape[-1]
@@ -608,15 +679,14 @@ class _RMSNormRes(torch.autograd.Function):
             N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
                                             y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
         ctx.save_for_backward(xc, w, rstd)
+        ctx.drop = drop if xc.data_ptr() == x.data_ptr() else None
         return y, xc.view_as(xc)
 
     @staticmethod
     def backward(ctx, gy, gres):
         xc, w, rstd = ctx.saved_tensors
         if gy is None:
-            return gres, None, None
-        d = xc.shape[-1]
-        T = xc.numel() // d
+            return gres, None, None, None
         g = gy.contiguous()
         if g.dtype != xc.dtype:
             g = g.to(xc.dtype)
@@ -625,19 +695,13 @@ class _RMSNormRes(torch.autograd.Function):
             r = gres.contiguous()
             if r.dtype != xc.dtype:
                 r = r.to(xc.dtype)
-        dx = torch.empty_like(xc)
-        dw = torch.empty(d, dtype=torch.float32, device=xc.device)
-        ws = torch.empty(N.lib().ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
-        with _Timed("rmsnorm.bwd", (4.0 if r is not None else 3.0) * T * d * xc.element_size()):
-            N.check(N.lib().ldm_rmsnorm_bwd(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
-                                            N.dtype_code(xc.dtype), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                            N.stream()), "ldm_rmsnorm_bwd")
-        return dx, dw, None
+        dx, dw = _rmsnorm_backward(xc, w, rstd, g, r, ctx.drop)
+        return dx, dw, None, None
 
 
 def rms_norm_with_residual(x: Tensor, weight: Tensor, eps: float) -> tuple[Tensor, Tensor]:
     """(rms_norm(x), x); use the second value as the residual-connection operand."""
-    return _RMSNormRes.apply(x, weight, eps)
+    return _RMSNormRes.apply(x, weight, eps, _input_drop(x))
 
 
 # ----------------------------------------------------------------------------
@@ -800,7 +864,7 @@ class _SwiGLUDown(torch.autograd.Function):
         else:
             g = torch.zeros(T, n_pad, dtype=dt, device=gy.device)
             g[:, :n].copy_(gy2)
-        g = _drop_grad(g, ctx.drop)
+        g = _drop_grad(g, ctx.drop, gy)
         dag = None
         if ctx.needs_input_grad[0]:
             dag = torch.empty_like(ag2)
@@ -829,8 +893,8 @@ def swiglu_down(ag: Tensor, pack: PackedWeights, residual: Tensor | None = None,
     ``h``: a * silu(g) if the caller has it (the second output of swiglu_up).  ``residual_dropout`` p > 0
     (with a residual): residual + dropout(w3(...), p)."""
     assert len(pack.weights) == 1
-    drop = (float(residual_dropout), _draw_seed()) if (residual is not None and residual_dropout > 0.0) else None
-    return _SwiGLUDown.apply(ag, h, residual, pack, drop, pack.weights[0], pack.biases[0])
+    drop = _new_drop(residual, residual_dropout)
+    return _tag_drop(_SwiGLUDown.apply(ag, h, residual, pack, drop, pack.weights[0], pack.biases[0]), drop)
 
 
 # ----------------------------------------------------------------------------

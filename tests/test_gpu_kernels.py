@@ -543,6 +543,105 @@ def test_dropout_add(dev, dtype, rows, d, p):
     assert float((out.detach()[~keep] - res.detach()[~keep]).abs().max()) == 0.0     # dropped: exactly the residual
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [True, False])
+@pytest.mark.parametrize("T,d,p", [(257, 768, 0.1), (64, 4096, 0.3), (1000, 64, 0.5), (4099, 2048, 0.1), (33, 8, 0.1)])
+def test_rmsnorm_bwd_with_dropout_gradient(dev, dtype, with_res, T, d, p):
+    """ldm_rmsnorm_bwd_dropgrad == ldm_rmsnorm_bwd followed by the masking pass ldm_dropout_add(dx, no residual),
+    bit for bit: dx, dw, and the masked copy (the backward of `src + self.dropout(...)` feeding the next norm,
+    src/transformer.py:352-361); widths the vector kernels do not take are declined."""
+    from src import _native as Nn
+    lib = Nn.lib()
+    torch.manual_seed(T + d)
+    seed = 0x0DD0_0000_0000_0000 + T * 131 + d
+    code = Nn.dtype_code(dtype)
+    x = torch.randn(T, d, device=dev).to(dtype)
+    dy = torch.randn(T, d, device=dev).to(dtype)
+    dres = torch.randn(T, d, device=dev).to(dtype) if with_res else None
+    w = torch.randn(d, device=dev)
+    rstd = torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6)
+    ws = torch.empty(lib.ldm_rmsnorm_bwd_ws_floats(T, d), device=dev)
+    dx1, dw1 = torch.empty_like(x), torch.empty(d, device=dev)
+    Nn.check(lib.ldm_rmsnorm_bwd(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), Nn.ptr(dres), T, d, code,
+                                 dx1.data_ptr(), dw1.data_ptr(), ws.data_ptr(), Nn.stream()), "ldm_rmsnorm_bwd")
+    m1 = torch.empty_like(x)
+    Nn.check(lib.ldm_dropout_add(dx1.data_ptr(), None, m1.data_ptr(), T, d, code, p, seed, Nn.stream()), "ldm_dropout_add")
+    dx2, dw2, m2 = torch.full_like(x, 7.0), torch.empty(d, device=dev), torch.full_like(x, 7.0)
+    Nn.check(lib.ldm_rmsnorm_bwd_dropgrad(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), Nn.ptr(dres), T, d,
+                                          code, dx2.data_ptr(), m2.data_ptr(), p, seed, dw2.data_ptr(), ws.data_ptr(),
+                                          Nn.stream()), "ldm_rmsnorm_bwd_dropgrad")
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+    assert torch.equal(m1, m2)
+    kept = float((m2 != 0).float().mean())
+    assert abs(kept - (1.0 - p)) < 4.0 * math.sqrt(p * (1 - p) / m2.numel()) + 2e-3
+    # a width that is not a multiple of 8 goes to the two-call form
+    rc = lib.ldm_rmsnorm_bwd_dropgrad(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), None, 4, 12, code,
+                                      dx2.data_ptr(), m2.data_ptr(), p, seed, dw2.data_ptr(), ws.data_ptr(), Nn.stream())
+    assert rc in (-2, -3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layer_dropout_backward_handoff_changes_nothing(dev, dtype):
+    """Two encoder layers + final norm in training mode with dropout 0.1: the masked gradient that the norm's
+    backward leaves for the projection behind the residual dropout gives the gradients of the two-pass form,
+    bit for bit, under the same torch seed -- and the hand-off is what ran (every residual dropout took it).
+    A tensor with a second consumer gets its gradient summed by autograd, so the projection masks it itself."""
+    from src import ops
+    from src.transformer import TransformerEncoderLayer, RMSNorm
+    torch.manual_seed(5)
+    d = 256
+    layers = torch.nn.ModuleList([TransformerEncoderLayer(d, 4, 512, dropout=0.1, layer_norm_eps=1e-6) for _ in range(2)]).to(dev)
+    norm = RMSNorm(d, eps=1e-6).to(dev)
+    for m in layers.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = dtype
+    layers.train()
+    x0 = torch.randn(2, 128, d, device=dev).to(dtype)
+    gout = torch.randn(2, 128, d, device=dev).to(dtype)
+
+    def run(fused, tap=False):
+        ops.FUSED_DROP_GRAD = fused
+        for prm in list(layers.parameters()) + list(norm.parameters()):
+            prm.grad = None
+        torch.manual_seed(99)
+        x = x0.clone().requires_grad_(True)
+        h = x
+        extra = 0.0
+        for layer in layers:
+            h = layer(h)
+            if tap:
+                extra = extra + h.float().sum() * 1e-3      # a second consumer of the layer's output
+        y = norm(h)
+        ((y * gout).float().sum() + extra).backward()
+        return x.grad.clone(), [prm.grad.clone() for prm in list(layers.parameters()) + list(norm.parameters())]
+
+    taken = []
+    orig_take = ops._Drop.take
+
+    def counting_take(self, gy, T, n):
+        r = orig_take(self, gy, T, n)
+        taken.append(r is not None)
+        return r
+    try:
+        ops._Drop.take = counting_take
+        gx_f, gp_f = run(True)
+        assert taken == [True] * 4
+        gx_t, gp_t = run(False)
+        assert torch.equal(gx_f, gx_t)
+        for a, b in zip(gp_f, gp_t):
+            assert torch.equal(a, b)
+        del taken[:]
+        gx_f2, gp_f2 = run(True, tap=True)
+        assert taken.count(False) == 2 and taken.count(True) == 2      # each layer's output has two consumers
+        gx_t2, gp_t2 = run(False, tap=True)
+        assert torch.equal(gx_f2, gx_t2)
+        for a, b in zip(gp_f2, gp_t2):
+            assert torch.equal(a, b)
+    finally:
+        ops._Drop.take = orig_take
+        ops.FUSED_DROP_GRAD = True
+
+
 @pytest.mark.parametrize("M,N,K,p,with_bias", [(512, 768, 768, 0.1, True), (8192, 2304, 256, 0.3, True),
                                                (1024, 256, 1024, 0.5, False)])
 def test_gemm_dropout_residual(dev, M, N, K, p, with_bias):
