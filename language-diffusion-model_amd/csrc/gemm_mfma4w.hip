@@ -51,10 +51,17 @@ typedef int i4s_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 256, KH = 32, NSLOT = 5;
 constexpr int HT_A = BM * 64, HT_B = BN * 64, HT = HT_A + HT_B;
 constexpr int LDS_BYTES = NSLOT * HT;
-constexpr int NOW = 8;              // quads stored while the others are packed
-constexpr int SPS = 4;              // deferred stores per step
+#ifndef LDM4W_NOW
+#define LDM4W_NOW 8
+#endif
+#ifndef LDM4W_SPS
+#define LDM4W_SPS 4
+#endif
+constexpr int NOW = LDM4W_NOW;      // quads stored while the others are packed (one behind every 32 / NOW packed quads)
+constexpr int SPS = LDM4W_SPS;      // deferred stores per step
 constexpr int NSS = (32 - NOW) / SPS;   // steps that carry deferred stores
 static_assert((32 - NOW) % SPS == 0 && NSS % 2 == 0, "whole pairs of store steps");
+static_assert(32 % NOW == 0 && 4 % SPS == 0, "stores at a fixed stride");
 
 struct WArgs {
   int64_t M, N, K;
@@ -65,7 +72,19 @@ struct WArgs {
   const bf16_t *R;    // nullable: residual [M, N] with the row stride of C, added before the rounding to bf16
   const int *dyn_m;   // nullable: device-side row count; only the m-tiles that hold rows < *dyn_m are walked
   int tiles_m, tiles_n, band_m;
+#ifdef LDM_GEMM_TIMING
+  unsigned long long *timing;   // [4 waves][8]: cycle totals of workgroup 17's per-item segments
+#endif
 };
+
+// Experiment builds (-DLDM_GEMM_TIMING): cycle totals of the per-item segments of workgroup 17 are added to the
+// device address given in the environment variable LDM_GEMM4W_TIMING_BUF.
+#ifdef LDM_GEMM_TIMING
+#define TSTAMP4(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); \
+                          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define TSTAMP4(var) do { } while (0)
+#endif
 
 __device__ __forceinline__ int swz_kc(int row) { return 3 * ((row >> 2) & 1); }
 
@@ -105,7 +124,8 @@ __device__ __forceinline__ TileId decode_item(int w, int total, int tiles_m, int
 template <int V> using IC = std::integral_constant<int, V>;
 
 // WR: the wave (0..3); wave (wm, wn) = (WR >> 1, WR & 1) owns rows wm * 128.., columns wn * 128.. of the tile
-template <int WR, bool RESID>
+// BIAS = false: no bias loads and no bias additions in the packing (the input-gradient products)
+template <int WR, bool RESID, bool BIAS>
 __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
   constexpr int wave = WR, wm = WR >> 1, wn = WR & 1;
   int tiles_m = g.tiles_m;
@@ -199,10 +219,12 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
   prologue(tid);
   bool first_item = true;
 
+  [[maybe_unused]] unsigned long long ts[6], tsum[6] = {0, 0, 0, 0, 0, 0}, tsum6 = 0, tsum7 = 0;
   while (true) {
     const int64_t m0 = (int64_t)tid.tm * BM, n0 = (int64_t)tid.tn * BN;
     f4_t acc[8][8];
     bf8_t fa[2][8], fb[2][8];
+    TSTAMP4(ts[0]);
 
     // half-tiles 0, 1 landed.  Issue order of this wave's vector-memory instructions: [bias loads] |
     // prologue (32) | stores of the packing phase (NOW, not before the first item) | step 0 ...: younger than
@@ -220,6 +242,7 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
         fb[0][i] = frag(va, HT_A + wn * 8192 + i * 1024);
       }
     }
+    TSTAMP4(ts[1]);
 
     // One 32-deep step: MFMAs on the fragments of half-tile p (set cur) with, in the gaps, the reads of
     // half-tile p+1 (set nxt), this step's LDS-DMA and deferred stores.
@@ -267,7 +290,8 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
           if constexpr (do_issue) dma(IC<j>{}, cur == 1, gq == 2 * WR ? voff : voff2);
           else if constexpr (rq >= 0) res_load(IC<rq + 2 * j + (gq - 2 * WR)>{});
         } else if constexpr (gq == gst) {
-          if constexpr (sq >= 0 && j < SPS) store_q(pk[sq + j], srd_prev, soff, IC<(sq + j) % 4>{});
+          // (SPS stores per step, evenly over its four periods; the quads of one step lie in one 16-row block)
+          if constexpr (sq >= 0 && j % (4 / SPS) == 0) store_q(pk[sq + j / (4 / SPS)], srd_prev, soff, IC<(sq + j / (4 / SPS)) % 4>{});
         } else {
           // rank of this gap among the period's free gaps
           constexpr int rank = gq - (gq > 2 * WR ? 1 : 0) - (gq > 2 * WR + 1 ? 1 : 0) - (gq > gst ? 1 : 0);
@@ -305,12 +329,15 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
       }
     };
     store_steps(store_steps, IC<0>{});
+    [[maybe_unused]] unsigned long long tm1, tm2;
+    TSTAMP4(tm1);
     int p = NSS;
     // steps up to np-5 send (the pairs up to (np-2, np-1)); the last four send nothing
     for (; p < np - 4; p += 2) {
       step(IC<0>{}, F_{}, T_{}, IC<-1>{}, p, IC<-1>{});
       step(IC<1>{}, F_{}, T_{}, IC<-1>{}, p + 1, IC<-1>{});
     }
+    TSTAMP4(tm2);
     // the last four steps send no LDS-DMA; with a residual their request gaps carry its 32 quads, which land in
     // the registers of the packed output (free since the deferred stores of the item before went out)
     if constexpr (RESID) {
@@ -327,11 +354,12 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
     }
     // (the asm MFMAs' results: wait states the compiler does not count)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    TSTAMP4(ts[2]);
 
     // bias of this lane's accumulator columns (four consecutive ones per fragment), requested before the
     // next item's prologue and waited for, counted, behind it
-    f4_t bv[8];
-    const bool has_bias = g.bias != nullptr;
+    [[maybe_unused]] f4_t bv[8];
+    const bool has_bias = BIAS && g.bias != nullptr;
     if (has_bias) {
       const float *bb = g.bias + n0 + wn * 128;
 #pragma unroll
@@ -345,14 +373,18 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
       tid = decode_item(w, total, tiles_m, g.tiles_n, g.band_m);
       prologue(tid);
     }
+    TSTAMP4(ts[3]);
     if (has_bias) {
       if (more) wait_vm<32>(); else wait_vm<0>();
       asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
     } else {
       if constexpr (RESID) { if (more) wait_vm<32>(); else wait_vm<0>(); }
+      if constexpr (BIAS) {
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) bv[ni] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 8; ++ni) bv[ni] = f4_t{0.f, 0.f, 0.f, 0.f};
+      }
     }
+    TSTAMP4(ts[4]);
     // (the residual quads are older than the bias requests and the next item's prologue: they have landed)
     // Pack: quad j = (16-row block j / 4, 64-byte group j % 4) = fragments 2t and 2t+1 (t = j % 4) of block
     // mi = j / 4.  A lane holds, per fragment, four consecutive columns of row lane & 15 at column group
@@ -384,7 +416,8 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
         constexpr int j = decltype(J)::value;
         if constexpr (j < 32) {
           constexpr int mi = j / 4, t = j % 4;
-          f4_t a = rd(acc[2 * t][mi]) + bv[2 * t], b = rd(acc[2 * t + 1][mi]) + bv[2 * t + 1];
+          f4_t a = rd(acc[2 * t][mi]), b = rd(acc[2 * t + 1][mi]);
+          if constexpr (BIAS) { a += bv[2 * t]; b += bv[2 * t + 1]; }
           if constexpr (RESID) {
             // the residual quad has the layout of the packed output; the same exchange of 16-lane rows takes
             // it back to the accumulators' layout (the exchange is its own inverse)
@@ -402,7 +435,8 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
           const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
           pk[j][0] = r0[0]; pk[j][1] = r1[0]; pk[j][2] = r0[1]; pk[j][3] = r1[1];
           // the first NOW quads leave while the others are packed: one store behind every fourth packed quad
-          if constexpr (j % 4 == 3 && j / 4 < NOW) store_q(pk[j / 4], srd, (unsigned)((j / 4) / 4) * ldc16, IC<(j / 4) % 4>{});
+          constexpr int every = 32 / NOW;
+          if constexpr (j % every == every - 1) store_q(pk[j / every], srd, (unsigned)((j / every) / 4) * ldc16, IC<(j / every) % 4>{});
           __builtin_amdgcn_sched_barrier(0);
           self(self, IC<j + 1>{});
         }
@@ -421,19 +455,34 @@ __device__ __forceinline__ void gemm4w_body(const WArgs &g, char *smem) {
         flush(flush, IC<NOW>{});
       }
     }
+#ifdef LDM_GEMM_TIMING
+    TSTAMP4(ts[5]);
+    for (int i = 0; i < 5; ++i) tsum[i] += ts[i + 1] - ts[i];
+    tsum[5] += 1;
+    tsum6 += tm1 - ts[1];
+    tsum7 += ts[2] - tm2;
+#endif
     if (!more) break;
   }
+#ifdef LDM_GEMM_TIMING
+  if (g.timing && blockIdx.x == 17 && lane == 0)
+  {
+    for (int i = 0; i < 6; ++i) atomicAdd(g.timing + wave * 8 + i, tsum[i]);
+    atomicAdd(g.timing + wave * 8 + 6, tsum6);     // of the main loop: the steps that carry deferred stores
+    atomicAdd(g.timing + wave * 8 + 7, tsum7);     // and the last four (no LDS-DMA)
+  }
+#endif
 }
 
-template <bool RESID>
+template <bool RESID, bool BIAS>
 __global__ __launch_bounds__(256, 1) void gemm4w_k(WArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // one copy of the code per wave: the copies differ in which gap of a step holds what
-  if (wave == 0) gemm4w_body<0, RESID>(g, smem);
-  else if (wave == 1) gemm4w_body<1, RESID>(g, smem);
-  else if (wave == 2) gemm4w_body<2, RESID>(g, smem);
-  else gemm4w_body<3, RESID>(g, smem);
+  if (wave == 0) gemm4w_body<0, RESID, BIAS>(g, smem);
+  else if (wave == 1) gemm4w_body<1, RESID, BIAS>(g, smem);
+  else if (wave == 2) gemm4w_body<2, RESID, BIAS>(g, smem);
+  else gemm4w_body<3, RESID, BIAS>(g, smem);
 }
 
 int num_cus4() {
@@ -477,6 +526,9 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
   g.R = (const bf16_t *)R;
   g.dyn_m = dyn_m;
   g.tiles_m = (int)tm; g.tiles_n = (int)tn;
+#ifdef LDM_GEMM_TIMING
+  { const char *tb = getenv("LDM_GEMM4W_TIMING_BUF"); g.timing = tb ? (unsigned long long *)strtoull(tb, nullptr, 0) : nullptr; }
+#endif
   {
     // m-tiles per band of the tile walk: at most 8, fewer while the band's A panel exceeds 8 MB (measured at
     // M = 262144, one box: K = 768 -- N = 768: 290 us at 8 against 302 at 16; N = 2304: 829 against 998;
@@ -489,14 +541,16 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
   static std::atomic<uint64_t> attr_done{0};
   uint64_t dev_bit;
   if (ldm_attr_pending(attr_done, &dev_bit)) {
-    (void)hipFuncSetAttribute((const void *)gemm4w_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void *)gemm4w_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)gemm4w_k<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)gemm4w_k<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)gemm4w_k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   const int64_t items = tm * tn;
   const int64_t nwg = items < num_cus4() ? items : num_cus4();   // persistent: one workgroup per CU
-  if (R) hipLaunchKernelGGL(gemm4w_k<true>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
-  else hipLaunchKernelGGL(gemm4w_k<false>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
+  if (R) hipLaunchKernelGGL((gemm4w_k<true, true>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
+  else if (bias) hipLaunchKernelGGL((gemm4w_k<false, true>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
+  else hipLaunchKernelGGL((gemm4w_k<false, false>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
   LDM_CHECK_LAUNCH();
   return LDM_OK;
 }
