@@ -145,6 +145,45 @@ def test_head_link_travels_with_the_tensor_not_with_addresses():
     assert b.grad is None and b.zero_padded is None and not b.compact_ok
 
 
+def test_dropout_gradient_handoff_is_taken_only_for_the_very_gradient_it_was_made_from():
+    """The masked gradient a norm's backward leaves for the projection behind a residual dropout (ops._Drop) is
+    used only when the gradient autograd delivers is the norm's dx itself: same storage, same size and dtype,
+    not modified since; it is handed out once and every other case falls back to the masking pass."""
+    import torch
+    from src import ops
+    T, n = 6, 8
+
+    def filled():
+        d = ops._Drop(0.1, 1234)
+        dx, dxd = torch.randn(T, n), torch.randn(T, n)
+        d.dx, d.dx_drop, d.ver = dx, dxd, dx._version
+        return d, dx, dxd
+
+    assert tuple(ops._Drop(0.25, 7)) == (0.25, 7)
+    assert ops._Drop(0.25, 7).take(torch.zeros(T, n), T, n) is None          # nothing was left
+    d, dx, dxd = filled()
+    got = d.take(dx.view(2, 3, n), T, n)                                     # (a view of dx: what a reshape's backward delivers)
+    assert got is not None and got.data_ptr() == dxd.data_ptr() and got.shape == (T, n)
+    assert d.dx is None and d.take(dx, T, n) is None                         # handed out once
+    d, dx, _ = filled()
+    assert d.take(dx + 1.0, T, n) is None                                    # a summed gradient is another tensor
+    d, dx, _ = filled()
+    dx.add_(1.0)
+    assert d.take(dx, T, n) is None                                          # modified in place since
+    d, dx, _ = filled()
+    assert d.take(dx[:3], 3, n) is None and d.dx is None                     # another size; the link is cleared anyway
+    d, dx, _ = filled()
+    assert d.take(dx.t(), n, T) is None                                      # not the row layout
+    # a tensor without the tag, or with gradients off, hands the norm nothing
+    x = torch.zeros(2, 3)
+    assert ops._input_drop(x) is None
+    ops._tag_drop(x, d)
+    assert ops._input_drop(x) is d
+    with torch.no_grad():
+        assert ops._input_drop(x) is None
+    assert ops._new_drop(None, 0.1) is None and ops._new_drop(x, 0.0) is None and ops._new_drop(x, 0.1).p == 0.1
+
+
 def test_bench_launches_its_own_ranks(tmp_path, monkeypatch):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts N ranks under
     torch.distributed.run from a parent that has not imported torch, and returns their exit code."""
