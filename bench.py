@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--objective", default="reference", choices=["reference", "paper"],
                     help="reference: one scalar t per step, unweighted mean over masked positions; paper: "
                          "per-sequence t ~ U(eps,1), 1/t weights, B*L normaliser")
+    ap.add_argument("--fp32-residual", action="store_true",
+                    help="keep the residual stream in fp32 around the bf16 sublayers (DiffusionTransformer.fp32_residual)")
     ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
                     help="hip: src.optim.FusedAdamW (one HIP pass, weight copies refreshed in it); torch: torch.optim.AdamW(fused=True)")
     args = ap.parse_args()
@@ -221,6 +223,7 @@ def main():
     random.seed(42)     # the reference seeds both identically on every rank (main.py:39-40)
     tr = DiffusionTransformer(DiffusionTransformerConfig(dropout=args.dropout, layer_norm_eps=1e-12,
                                                          max_position_embeddings=max(512, args.seq), **cfg))
+    tr.fp32_residual = bool(args.fp32_residual)
     tok = types.SimpleNamespace(mask_token_id=103, bos_token_id=101, eos_token_id=102, pad_token_id=0)
     model = DiffusionLanguageModel(tr, tok, create_masking_strategy("random", 101, 102, 0, 103), None)
     acc = HipAccelerator(mixed_precision="bf16" if args.dtype == "bf16" else "no", device=dev,
@@ -346,6 +349,7 @@ def main():
                        else f"{args.config} model, seq {args.seq}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": args.seq,
                        "parallelism": f"dp{world}", "dropout": args.dropout, "objective": args.objective,
+                       "residual_stream": "fp32" if args.fp32_residual else args.dtype,
                        "optimizer": "AdamW(lr=5e-4, wd=0.1)", **cfg},
             "ranks_seen": ranks_seen,
             "grad_buckets": model.num_buckets if isinstance(model, GradBucketDataParallel) else 0,

@@ -91,6 +91,16 @@ int ldm_rmsnorm_bwd_dropgrad(const void *x, const float *w, const float *rstd, c
                              void *dx_drop, float p, uint64_t seed, float *dw, float *dw_partial,
                              void *stream);
 
+/* RMSNorm between an fp32 residual stream and bf16 projections: x fp32 -> y bf16, statistics and products
+ * in fp32 -- what the reference's norm is under bf16 autocast (src/transformer.py:54-58 run in fp32, the
+ * Linear behind it casts its input).  Backward: x, dres (nullable) and dx fp32, dy bf16; dw / dw_partial as
+ * ldm_rmsnorm_bwd.  d % 8 == 0 and d <= 4096, else LDM_E_SHAPE. */
+int ldm_rmsnorm_fwd_f32_bf16(const float *x, const float *w, int64_t T, int64_t d, float eps, void *y,
+                             float *rstd, void *stream);
+int ldm_rmsnorm_bwd_f32_bf16(const float *x, const float *w, const float *rstd, const void *dy,
+                             const float *dres, int64_t T, int64_t d, float *dx, float *dw,
+                             float *dw_partial, void *stream);
+
 /* ldm_rmsnorm_bwd for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): the same kernels and results, but the dw partials live in a
  * fixed 8 MiB device array inside the library instead of a caller-provided workspace, so the call

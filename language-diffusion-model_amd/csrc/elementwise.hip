@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T *x, const float *w,
 
 // 8-element-vector forms (d % 8 == 0): 16-byte accesses for bf16, every load of a row issued
 // before the first use, rows kept in storage form in registers.  NV = vectors per lane.
-template <typename T, int NV>
+// TO: the type of y (T, or bf16 under an fp32 x: the norm between an fp32 residual stream and a bf16 projection)
+template <typename T, int NV, typename TO = T>
 __global__ __launch_bounds__(256) void rmsnorm_fwd8_k(const T *x, const float *w, int64_t rows, int d, float eps,
-                                                      T *y, float *rstd) {
+                                                      TO *y, float *rstd) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd8_k(const T *x, const float *w
     ss = wave_sum(ss);
     const float rs = 1.0f / sqrtf(ss / (float)d + eps);
     if (lane == 0) rstd[r] = rs;
-    T *yr = y + r * d;
+    TO *yr = y + r * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int vi = lane + i * 64;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd8_k(const T *x, const float *w
           o[j] = g0.v[j] * (v[i].get(j) * rs);
           o[j + 4] = g1.v[j] * (v[i].get(j + 4) * rs);
         }
-        Raw8<T>::store(yr + vi * 8, o);
+        Raw8<TO>::store(yr + vi * 8, o);
       }
     }
   }
@@ -212,8 +213,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd8_k(const T *x, const float *w
 // projection's backward needs, written here instead of by a masking pass of its own over dx.
 struct RmsDrop { void *dx_drop; unsigned thresh, seed_lo, seed_hi; float inv; };
 
-template <typename T, int NV, bool RES, bool DROP>
-__global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w, const float *rstd, const T *dy,
+// TG: the type of dy (T, or bf16 under fp32 x / dres / dx: the fp32 residual stream's norm, see rmsnorm_fwd8_k)
+template <typename T, int NV, bool RES, bool DROP, typename TG = T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w, const float *rstd, const TG *dy,
                                                       const T *dres, int64_t rows, int d, T *dx,
                                                       float *dw_partial, RmsDrop dr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][d]
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd8_k(const T *x, const float *w
   const float inv_d = 1.0f / (float)d;
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float rs = rstd[r];
-    Raw8<T> xv[NV], gv[NV], rv[NV];
+    Raw8<T> xv[NV], rv[NV];
+    Raw8<TG> gv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int vi = lane + i * 64;
@@ -837,6 +840,69 @@ extern "C" int ldm_rmsnorm_fwd(const void *x, const float *w, int64_t T, int64_t
   if (dtype == LDM_F32) return rmsnorm_fwd_launch<float>(x, w, T, d, eps, y, rstd, s);
   if (dtype == LDM_BF16) return rmsnorm_fwd_launch<bf16_t>(x, w, T, d, eps, y, rstd, s);
   return LDM_E_DTYPE;
+}
+
+// RMSNorm between an fp32 residual stream and bf16 projections: x fp32 -> y bf16 (statistics and products in
+// fp32, one rounding), the form the reference's norm takes under bf16 autocast (src/transformer.py:54-58 run in
+// fp32, the Linear behind it casts).  16-byte-vector kernels only: d % 8 == 0, d <= 4096.
+extern "C" int ldm_rmsnorm_fwd_f32_bf16(const float *x, const float *w, int64_t T, int64_t d, float eps, void *y,
+                                        float *rstd, void *stream) {
+  if (T < 0 || d <= 0) return LDM_E_BADARG;
+  if (T == 0) return LDM_OK;
+  if (!x || !w || !y || !rstd) return LDM_E_BADARG;
+  if (d % 8 || rms_nv8(d) > 8) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(y, 16) || !aligned_to(w, 16)) return LDM_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = stream_grid(T, 4);
+#define RMS_FM(NV) hipLaunchKernelGGL((rmsnorm_fwd8_k<float, NV, bf16_t>), dim3(grid), dim3(256), 0, s, x, w, T, (int)d, eps, (bf16_t *)y, rstd)
+  switch (rms_nv8(d)) {
+    case 1: RMS_FM(1); break;
+    case 2: RMS_FM(2); break;
+    case 4: RMS_FM(4); break;
+    default: RMS_FM(8); break;
+  }
+#undef RMS_FM
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
+}
+
+// its backward: x, dres (nullable), dx fp32; dy bf16.  dw / dw_partial as ldm_rmsnorm_bwd.
+extern "C" int ldm_rmsnorm_bwd_f32_bf16(const float *x, const float *w, const float *rstd, const void *dy,
+                                        const float *dres, int64_t T, int64_t d, float *dx, float *dw,
+                                        float *dw_partial, void *stream) {
+  if (T < 0 || d <= 0) return LDM_E_BADARG;
+  if (!dw) return LDM_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 0) return (int)hipMemsetAsync(dw, 0, d * sizeof(float), s);
+  if (!x || !w || !rstd || !dy || !dx || !dw_partial) return LDM_E_BADARG;
+  if (d % 8 || rms_nv8(d) > 8) return LDM_E_SHAPE;
+  if (!aligned_to(x, 16) || !aligned_to(dy, 16) || !aligned_to(dx, 16) || !aligned_to(w, 16) || (dres && !aligned_to(dres, 16)))
+    return LDM_E_ALIGN;
+  int64_t blocks = ceil_div(T, 4);
+  if (blocks > kRmsBwdBlocks) blocks = kRmsBwdBlocks;
+  const unsigned grid = (unsigned)blocks;
+  const size_t lds = (size_t)4 * d * sizeof(float);
+  const RmsDrop nodrop{nullptr, 0u, 0u, 0u, 1.0f};
+#define RMS_BM(NV)                                                                                                  \
+  do {                                                                                                              \
+    if (dres)                                                                                                       \
+      hipLaunchKernelGGL((rmsnorm_bwd8_k<float, NV, true, false, bf16_t>), dim3(grid), dim3(256), lds, s, x, w, rstd, \
+                         (const bf16_t *)dy, dres, T, (int)d, dx, dw_partial, nodrop);                              \
+    else                                                                                                            \
+      hipLaunchKernelGGL((rmsnorm_bwd8_k<float, NV, false, false, bf16_t>), dim3(grid), dim3(256), lds, s, x, w, rstd, \
+                         (const bf16_t *)dy, dres, T, (int)d, dx, dw_partial, nodrop);                              \
+  } while (0)
+  switch (rms_nv8(d)) {
+    case 1: RMS_BM(1); break;
+    case 2: RMS_BM(2); break;
+    case 4: RMS_BM(4); break;
+    default: RMS_BM(8); break;
+  }
+#undef RMS_BM
+  LDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)ceil_div(d, 32)), dim3(1024), 0, s, dw_partial, (int64_t)grid, d, dw);
+  LDM_CHECK_LAUNCH();
+  return LDM_OK;
 }
 
 extern "C" int64_t ldm_rmsnorm_bwd_ws_floats(int64_t T, int64_t d) {

@@ -131,7 +131,7 @@ extern "C" int ldm_gemm_qkv_rope(int64_t T, int64_t D, int64_t K, int64_t hd, in
                                         ld_qkv, (hipStream_t)stream);
 }
 
-extern "C" int ldm_abi_version(void) { return 20; }
+extern "C" int ldm_abi_version(void) { return 21; }
 
 extern "C" const char *ldm_error_string(int code) {
   switch (code) {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 20   # what ldm_abi_version() of a matching library returns
+ABI_VERSION = 21   # what ldm_abi_version() of a matching library returns
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -42,6 +42,8 @@ SIGNATURES = {
     "ldm_rmsnorm_bwd_ws_floats": (_i64, [_i64, _i64]),
     "ldm_rmsnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ldm_rmsnorm_bwd_dropgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _u64, _vp, _vp, _vp]),
+    "ldm_rmsnorm_fwd_f32_bf16": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "ldm_rmsnorm_bwd_f32_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "ldm_rmsnorm_bwd_noalloc_max_d": (_i64, []),
     "ldm_rmsnorm_bwd_noalloc": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "ldm_rope_qk": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _f32, _i32, _vp]),

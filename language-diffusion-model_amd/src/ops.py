@@ -598,8 +598,34 @@ def embedding(ids: Tensor, table: Tensor, out_dtype: torch.dtype, hot_id: int = 
 
 
 # ----------------------------------------------------------------------------
-def _rmsnorm_backward(xc, w, rstd, g, r, drop):
-    """dx (+ r), dw of the norm; with ``drop`` (a _Drop) also the masked copy of dx, left in ``drop``."""
+def _rmsnorm_forward(xc, w, eps, out_dtype):
+    """(y, rstd, mixed): y in ``out_dtype`` (None: x's).  mixed: fp32 x -> bf16 y out of one kernel (the norm
+    between an fp32 residual stream and a bf16 projection); other combinations are the norm in x's dtype
+    followed by a cast."""
+    d = xc.shape[-1]
+    T = xc.numel() // d
+    lib = N.lib()
+    rstd = torch.empty(T, dtype=torch.float32, device=xc.device)
+    if out_dtype is not None and out_dtype != xc.dtype and xc.dtype == torch.float32 and out_dtype == torch.bfloat16:
+        y = torch.empty(xc.shape, dtype=torch.bfloat16, device=xc.device)
+        with _Timed("rmsnorm.fwd", 6.0 * T * d) as tm:
+            rc = lib.ldm_rmsnorm_fwd_f32_bf16(xc.data_ptr(), w.data_ptr(), T, d, eps, y.data_ptr(), rstd.data_ptr(), N.stream())
+            tm.declined = rc in (-2, -3)
+        if rc not in (-2, -3):
+            N.check(rc, "ldm_rmsnorm_fwd_f32_bf16")
+            return y, rstd, True
+    y = torch.empty_like(xc)
+    with _Timed("rmsnorm.fwd", 2.0 * T * d * xc.element_size()):
+        N.check(lib.ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype), y.data_ptr(),
+                                    rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+    if out_dtype is not None and out_dtype != y.dtype:
+        y = y.to(out_dtype)
+    return y, rstd, False
+
+
+def _rmsnorm_backward(xc, w, rstd, g, r, drop, mixed=False):
+    """dx (+ r), dw of the norm; with ``drop`` (a _Drop) also the masked copy of dx, left in ``drop``.
+    ``mixed``: the forward was the fp32 -> bf16 kernel; g is then taken in bf16, x / r / dx are fp32."""
     d = xc.shape[-1]
     T = xc.numel() // d
     es = xc.element_size()
@@ -608,6 +634,16 @@ def _rmsnorm_backward(xc, w, rstd, g, r, drop):
     dw = torch.empty(d, dtype=torch.float32, device=xc.device)
     ws = torch.empty(lib.ldm_rmsnorm_bwd_ws_floats(T, d), dtype=torch.float32, device=xc.device)
     nbuf = 4.0 if r is not None else 3.0
+    if mixed:
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        with _Timed("rmsnorm.bwd", ((nbuf - 1.0) * 4.0 + 2.0) * T * d):
+            N.check(lib.ldm_rmsnorm_bwd_f32_bf16(xc.data_ptr(), w.data_ptr(), rstd.data_ptr(), g.data_ptr(), N.ptr(r), T, d,
+                                                 dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), N.stream()),
+                    "ldm_rmsnorm_bwd_f32_bf16")
+        return dx, dw
+    if g.dtype != xc.dtype:
+        g = g.to(xc.dtype)
     if drop is not None and FUSED_DROP_GRAD and T > 0:
         dxd = torch.empty_like(xc)
         with _Timed("rmsnorm.bwd", (nbuf + 1.0) * T * d * es) as tm:
@@ -632,17 +668,11 @@ def _input_drop(x):
 
 class _RMSNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, eps, drop=None):
+    def forward(ctx, x, weight, eps, drop=None, out_dtype=None):
         N.require_device(x, weight)
         xc = x.contiguous()
-        d = xc.shape[-1]
-        T = xc.numel() // d
-        y = torch.empty_like(xc)
-        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
         w = weight.detach().float().contiguous()
-        with _Timed("rmsnorm.fwd", 2.0 * T * d * xc.element_size()):
-            N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
-                                            y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+        y, rstd, ctx.mixed = _rmsnorm_forward(xc, w, eps, out_dtype)
         ctx.save_for_backward(xc, w, rstd)
         ctx.drop = drop if xc.data_ptr() == x.data_ptr() else None
         return y
@@ -650,15 +680,13 @@ class _RMSNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         xc, w, rstd = ctx.saved_tensors
-        g = gy.contiguous()
-        if g.dtype != xc.dtype:
-            g = g.to(xc.dtype)
-        dx, dw = _rmsnorm_backward(xc, w, rstd, g, None, ctx.drop)
-        return dx, dw, None, None
+        dx, dw = _rmsnorm_backward(xc, w, rstd, gy.contiguous(), None, ctx.drop, ctx.mixed)
+        return dx, dw, None, None, None
 
 
-def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
-    return _RMSNorm.apply(x, weight, eps, _input_drop(x))
+def rms_norm(x: Tensor, weight: Tensor, eps: float, out_dtype: torch.dtype | None = None) -> Tensor:
+    """``out_dtype``: dtype of the result (default x's); fp32 x with a bf16 result is one kernel."""
+    return _RMSNorm.apply(x, weight, eps, _input_drop(x), out_dtype)
 
 
 class _RMSNormRes(torch.autograd.Function):
@@ -667,17 +695,11 @@ class _RMSNormRes(torch.autograd.Function):
     kernel instead of by a separate elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, eps, drop=None):
+    def forward(ctx, x, weight, eps, drop=None, out_dtype=None):
         N.require_device(x, weight)
         xc = x.contiguous()
-        d = xc.shape[-1]
-        T = xc.numel() // d
-        y = torch.empty_like(xc)
-        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
         w = weight.detach().float().contiguous()
-        with _Timed("rmsnorm.fwd", 2.0 * T * d * xc.element_size()):
-            N.check(N.lib().ldm_rmsnorm_fwd(xc.data_ptr(), w.data_ptr(), T, d, eps, N.dtype_code(xc.dtype),
-                                            y.data_ptr(), rstd.data_ptr(), N.stream()), "ldm_rmsnorm_fwd")
+        y, rstd, ctx.mixed = _rmsnorm_forward(xc, w, eps, out_dtype)
         ctx.save_for_backward(xc, w, rstd)
         ctx.drop = drop if xc.data_ptr() == x.data_ptr() else None
         return y, xc.view_as(xc)
@@ -686,22 +708,21 @@ class _RMSNormRes(torch.autograd.Function):
     def backward(ctx, gy, gres):
         xc, w, rstd = ctx.saved_tensors
         if gy is None:
-            return gres, None, None, None
+            return gres, None, None, None, None
         g = gy.contiguous()
-        if g.dtype != xc.dtype:
-            g = g.to(xc.dtype)
         r = None
         if gres is not None:
             r = gres.contiguous()
             if r.dtype != xc.dtype:
                 r = r.to(xc.dtype)
-        dx, dw = _rmsnorm_backward(xc, w, rstd, g, r, ctx.drop)
-        return dx, dw, None, None
+        dx, dw = _rmsnorm_backward(xc, w, rstd, g, r, ctx.drop, ctx.mixed)
+        return dx, dw, None, None, None
 
 
-def rms_norm_with_residual(x: Tensor, weight: Tensor, eps: float) -> tuple[Tensor, Tensor]:
+def rms_norm_with_residual(x: Tensor, weight: Tensor, eps: float,
+                           out_dtype: torch.dtype | None = None) -> tuple[Tensor, Tensor]:
     """(rms_norm(x), x); use the second value as the residual-connection operand."""
-    return _RMSNormRes.apply(x, weight, eps, _input_drop(x))
+    return _RMSNormRes.apply(x, weight, eps, _input_drop(x), out_dtype)
 
 
 # ----------------------------------------------------------------------------

@@ -67,13 +67,14 @@ class RMSNorm(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(dim))
 
-    def forward(self, x: Tensor) -> Tensor:
-        return ops.rms_norm(x, self.weight, self.eps)
+    def forward(self, x: Tensor, out_dtype: torch.dtype | None = None) -> Tensor:
+        """``out_dtype`` (an extension): dtype of the result, default x's."""
+        return ops.rms_norm(x, self.weight, self.eps, out_dtype)
 
-    def with_residual(self, x: Tensor) -> tuple[Tensor, Tensor]:
+    def with_residual(self, x: Tensor, out_dtype: torch.dtype | None = None) -> tuple[Tensor, Tensor]:
         """(norm(x), x): feeding the second value to the residual connection lets the norm's
         backward kernel add the residual-stream gradient itself."""
-        return ops.rms_norm_with_residual(x, self.weight, self.eps)
+        return ops.rms_norm_with_residual(x, self.weight, self.eps, out_dtype)
 
 
 class SwiGLU(nn.Module):
@@ -238,9 +239,21 @@ class TransformerEncoderLayer(nn.Module):
         self.norm2 = RMSNorm(d_model, eps=layer_norm_eps)
         self.swiglu = SwiGLU(d_model, dim_feedforward, d_model)
         self.dropout = nn.Dropout(dropout)
+        self.fp32_residual = False      # see DiffusionTransformer.fp32_residual
 
     def forward(self, src: Tensor, src_mask: Tensor | None = None,
                 src_key_padding_mask: Tensor | None = None) -> Tensor:
+        if self.fp32_residual and src.dtype == torch.float32 and self.self_attn.compute_dtype != torch.float32:
+            # fp32 residual stream around bf16 sublayers, as the reference runs under bf16 autocast (its
+            # RMSNorm and the additions of src/transformer.py:346-361 stay in fp32, only the Linears and the
+            # attention products are cast): norm of the fp32 stream, sublayer in bf16, fp32 addition
+            # (the additions promote the bf16 sublayer output to the stream's fp32 in the same pass)
+            dt = self.self_attn.compute_dtype
+            q, src = self.norm1.with_residual(src, dt)
+            h = self.self_attn(q, q, q, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)
+            src = src + self.dropout(h)
+            q, src = self.norm2.with_residual(src, dt)
+            return src + self.dropout(self.swiglu(q))
         if self.training and self.dropout.p > 0:
             # the two residual dropouts (src/transformer.py:352,361), each fused with its addition
             # and with the sublayer's last projection: the mask is applied in that GEMM's epilogue
@@ -287,6 +300,13 @@ class DiffusionTransformer(nn.Module):
         # (torch.utils.checkpoint): activation memory per layer drops from ~19 [T, d]-sized tensors to one,
         # for one extra forward pass.  Meant for the 8B shape at long batch; off by default.
         self.recompute_layers = False
+        # True (with a bf16 compute dtype): the residual stream -- embedding output, the two additions per layer,
+        # the norms' inputs and outputs -- is kept in fp32 and only the projections and the attention run in
+        # bf16, which is what the reference does under bf16 autocast.  The default keeps the stream in bf16 (the
+        # additions ride in the projection epilogues); at 16 layers that costs up to 2.5 x the reference's own
+        # bf16 deviation on single deep-layer gradient tensors, while loss and whole gradient stay within 2e-2.
+        # The fp32 stream runs its additions and casts as separate passes.
+        self.fp32_residual = False
 
     def _init_parameters(self) -> None:
         """Xavier-uniform on every parameter with dim() > 1 (src/transformer.py:407-411)."""
@@ -313,7 +333,11 @@ class DiffusionTransformer(nn.Module):
 
     def hidden_states(self, input_ids: Tensor, attention_mask: Tensor | None = None) -> Tensor:
         """Everything of forward() up to and including the final norm: [B,S,d]."""
-        x = ops.embedding(input_ids, self.embedding.weight, self.compute_dtype, self.hot_token_id)
+        stream32 = self.fp32_residual and self.compute_dtype != torch.float32
+        x = ops.embedding(input_ids, self.embedding.weight, torch.float32 if stream32 else self.compute_dtype,
+                          self.hot_token_id)
+        for layer in self.layers:
+            layer.fp32_residual = stream32
         key_padding_mask = None
         if attention_mask is not None:
             key_padding_mask = attention_mask == 0
@@ -333,10 +357,11 @@ class DiffusionTransformer(nn.Module):
             # the SAME masks only because checkpoint restores the generator state it recorded in forward
             for layer in self.layers:
                 x = checkpoint(run, layer, x, use_reentrant=False, preserve_rng_state=True)
-            return self.norm(x)
-        for layer in self.layers:
-            x = layer(x, src_key_padding_mask=key_padding_mask)
-        return self.norm(x)
+        else:
+            for layer in self.layers:
+                x = layer(x, src_key_padding_mask=key_padding_mask)
+        # (the head and its fused loss take the compute dtype)
+        return self.norm(x, self.compute_dtype) if stream32 else self.norm(x)
 
     # Accelerate wraps the reference's forward so that the bf16 logits of its autocast Linear come back as
     # fp32 (``convert_outputs_to_fp32``): the same values, up-cast after the fact.  ``fp32_logits = True``

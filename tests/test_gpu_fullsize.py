@@ -125,7 +125,7 @@ def default_case():
                 omask=omask, noise=noise)
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-fp32stream"])
 @pytest.mark.parametrize("head", ["dense", "fused"])
 def test_default_model_full_depth_matches_oracle(dev, default_case, mode, head):
     from src import ops
@@ -133,6 +133,7 @@ def test_default_model_full_depth_matches_oracle(dev, default_case, mode, head):
     c = default_case
     dtype = torch.float32 if mode == "fp32" else torch.bfloat16
     model = _model_from(c["params"], c["ocfg"], dev, dtype, 512)
+    model.transformer.fp32_residual = mode == "bf16-fp32stream"    # (the stream in fp32 around bf16 sublayers)
     model.masking_strategy = _InjectedDraw(model.masking_strategy, c["draw"].to(dev))
     ids, att = c["ids"].to(dev), c["att"].to(dev)
     t = torch.tensor([c["t"]])
@@ -140,14 +141,14 @@ def test_default_model_full_depth_matches_oracle(dev, default_case, mode, head):
     if head == "fused":
         loss = model.training_loss(ids, att, t=t)
         # fp32 declines the fused form (it is a bf16 MFMA path) and runs the dense composition
-        assert (ops.FUSED_HEAD_STATS["used"] == used0 + 1) == (mode == "bf16")
+        assert (ops.FUSED_HEAD_STATS["used"] == used0 + 1) == (mode != "fp32")
     else:
         logits, masked, mask = model(ids, att, t=t)
         assert torch.equal(masked.cpu(), c["omasked"]) and torch.equal(mask.cpu(), c["omask"])   # bit-exact
         loss = variational_lower_bound_loss(logits, ids, masked, 103, att)
     loss.backward()
     _compare(model, c["og"], c["ol"], loss.item(), 1e-5 if mode == "fp32" else 2e-2, f"default/{mode}/{head}",
-             ref_noise=c["noise"] if mode == "bf16" else None)
+             ref_noise=c["noise"] if mode != "fp32" else None)
 
 
 def test_one_1b_layer_at_seq_4096_matches_oracle(dev):
@@ -195,8 +196,10 @@ def test_1b_model_full_depth_matches_oracle(dev):
     ol, og, _, _, _ = so.step_loss_and_grads(params, ocfg, ids, att, t, draw)
     _, og16, _, _, _ = so.step_loss_and_grads(params, ocfg, ids, att, t, draw, autocast_bf16=True)
     noise = {n: rel_err(og16[n], og[n]) for n in og}
-    for mode, dtype, tol in (("fp32", torch.float32, 1e-5), ("bf16", torch.bfloat16, 2e-2)):
+    for mode, dtype, tol in (("fp32", torch.float32, 1e-5), ("bf16", torch.bfloat16, 2e-2),
+                             ("bf16-fp32stream", torch.bfloat16, 2e-2)):
         model = _model_from(params, ocfg, dev, dtype, S)
+        model.transformer.fp32_residual = mode == "bf16-fp32stream"
         model.masking_strategy = _InjectedDraw(model.masking_strategy, draw.to(dev))
         loss = model.training_loss(ids.to(dev), att.to(dev), t=torch.tensor([t]))
         loss.backward()
@@ -205,13 +208,16 @@ def test_1b_model_full_depth_matches_oracle(dev):
         # absolute figure is 1.4e-1 on layers.15 q_proj.weight; the default model's 8 layers stay within
         # 1.25 x): the residual stream is stored in bf16 here and in fp32 under autocast, and that rounding adds
         # up over 16 layers.  Held to 3 x; loss (1e-6) and whole gradient (1.2e-2) to the flat 2e-2.
+        # bf16 with the residual stream in fp32 (DiffusionTransformer.fp32_residual, the reference's own arrangement
+        # under autocast): every tensor within the reference's own bf16 deviation (measured 0.99 x at worst,
+        # 5.7e-2 on layers.15 q_proj.weight), held to the 1.5 x of the default model.
         # fp32, per tensor: the q/k projection gradients of the deep layers are small sums of cancelling terms,
         # and the fp32 oracle itself sits 1.1e-5 from an fp64 run of the same step on them (measured on the
         # host: layers.15 k_proj.weight 1.10e-5, q_proj.weight 1.07e-5; whole gradient 7.6e-7), so two fp32
         # computations cannot be asked to agree to 1e-5 there.  Loss and whole gradient are held to 1e-5.
         _compare(model, og, ol, loss.item(), tol, f"1b-full-depth/{mode}",
-                 ref_noise=noise if mode == "bf16" else None, tensor_tol=4e-5 if mode == "fp32" else None,
-                 noise_factor=3.0)
+                 ref_noise=noise if mode != "fp32" else None, tensor_tol=4e-5 if mode == "fp32" else None,
+                 noise_factor=BF16_NOISE_FACTOR if mode == "bf16-fp32stream" else 3.0)
         del model
         torch.cuda.empty_cache()
 
@@ -294,7 +300,7 @@ def test_two_models_interleaved_do_not_cross_wires(dev):
             assert rel_err(p.grad, ref[n]) < 5e-3, n       # float-atomic summation order only
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-fp32stream"])
 def test_recompute_layers_gives_the_same_step(dev, mode):
     """DiffusionTransformer.recompute_layers (keep only each layer's input, re-run its forward in backward):
     same loss, same gradients up to the run-to-run noise of the float-atomic weight gradients."""
@@ -306,6 +312,7 @@ def test_recompute_layers_gives_the_same_step(dev, mode):
     draw = torch.rand(B, S, generator=torch.Generator().manual_seed(23)).to(dev)
     dtype = torch.float32 if mode == "fp32" else torch.bfloat16
     model = _model_from(params, ocfg, dev, dtype, 512)
+    model.transformer.fp32_residual = mode == "bf16-fp32stream"
     model.masking_strategy = _InjectedDraw(model.masking_strategy, draw)
     out = {}
     for rc in (False, True):

@@ -580,6 +580,54 @@ def test_rmsnorm_bwd_with_dropout_gradient(dev, dtype, with_res, T, d, p):
     assert rc in (-2, -3)
 
 
+@pytest.mark.parametrize("with_res", [True, False])
+@pytest.mark.parametrize("T,d", [(257, 768), (64, 4096), (1000, 64), (4099, 2048), (33, 8)])
+def test_rmsnorm_fp32_stream_kernels(dev, with_res, T, d):
+    """The norm between an fp32 residual stream and bf16 projections (what src/transformer.py:54-58 is under
+    bf16 autocast): ldm_rmsnorm_fwd_f32_bf16 == the fp32 kernel's result rounded to bf16, and
+    ldm_rmsnorm_bwd_f32_bf16 == the fp32 backward kernel on the up-cast gradient, bit for bit; the autograd
+    wrapper uses them for fp32 input with a bf16 result."""
+    from src import _native as Nn, ops
+    lib = Nn.lib()
+    torch.manual_seed(T * 3 + d)
+    x = torch.randn(T, d, device=dev) * 3.0
+    w = torch.randn(d, device=dev)
+    dy = torch.randn(T, d, device=dev).bfloat16()
+    dres = torch.randn(T, d, device=dev) if with_res else None
+    y32, rstd32 = torch.empty_like(x), torch.empty(T, device=dev)
+    Nn.check(lib.ldm_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), T, d, 1e-6, Nn.F32, y32.data_ptr(), rstd32.data_ptr(), Nn.stream()), "fwd")
+    y16, rstd = torch.empty(T, d, device=dev, dtype=torch.bfloat16), torch.empty(T, device=dev)
+    Nn.check(lib.ldm_rmsnorm_fwd_f32_bf16(x.data_ptr(), w.data_ptr(), T, d, 1e-6, y16.data_ptr(), rstd.data_ptr(), Nn.stream()), "fwd mixed")
+    assert torch.equal(rstd, rstd32) and torch.equal(y16, y32.bfloat16())
+    ws = torch.empty(lib.ldm_rmsnorm_bwd_ws_floats(T, d), device=dev)
+    dx32, dw32 = torch.empty_like(x), torch.empty(d, device=dev)
+    g32 = dy.float()
+    Nn.check(lib.ldm_rmsnorm_bwd(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), g32.data_ptr(), Nn.ptr(dres), T, d, Nn.F32,
+                                 dx32.data_ptr(), dw32.data_ptr(), ws.data_ptr(), Nn.stream()), "bwd")
+    dx, dw = torch.full_like(x, 7.0), torch.empty(d, device=dev)
+    Nn.check(lib.ldm_rmsnorm_bwd_f32_bf16(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), Nn.ptr(dres), T, d,
+                                          dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), Nn.stream()), "bwd mixed")
+    assert torch.equal(dx, dx32) and torch.equal(dw, dw32)
+    # the autograd wrapper: fp32 in, bf16 out, fp32 gradient of the input
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    if with_res:
+        y, stream = ops.rms_norm_with_residual(xr, wr, 1e-6, torch.bfloat16)
+        (y.float() * dy.float()).sum().backward(retain_graph=True)
+        assert stream.dtype == torch.float32
+    else:
+        y = ops.rms_norm(xr, wr, 1e-6, torch.bfloat16)
+        y.backward(dy)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, y16) and xr.grad.dtype == torch.float32
+    if not with_res:
+        assert torch.equal(xr.grad, dx32) and torch.equal(wr.grad, dw32)
+    # widths the 16-byte-vector kernels do not take are declined by the entry point and composed by the wrapper
+    assert lib.ldm_rmsnorm_fwd_f32_bf16(x.data_ptr(), w.data_ptr(), 4, 12, 1e-6, y16.data_ptr(), rstd.data_ptr(), Nn.stream()) in (-2, -3)
+    x12 = torch.randn(5, 12, device=dev)
+    y12 = ops.rms_norm(x12, torch.ones(12, device=dev), 1e-6, torch.bfloat16)
+    assert y12.dtype == torch.bfloat16 and rel_err(y12.float(), x12 * torch.rsqrt(x12.pow(2).mean(-1, keepdim=True) + 1e-6)) < 4e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layer_dropout_backward_handoff_changes_nothing(dev, dtype):
     """Two encoder layers + final norm in training mode with dropout 0.1: the masked gradient that the norm's
