@@ -328,7 +328,8 @@ def test_recompute_layers_gives_the_same_step(dev, mode):
         assert rel_err(out[True][1][n], g) < (1e-6 if mode == "fp32" else 5e-3), n
 
 
-def test_recompute_layers_with_dropout_regenerates_the_same_masks(dev):
+@pytest.mark.parametrize("stream32", [False, True])
+def test_recompute_layers_with_dropout_regenerates_the_same_masks(dev, stream32):
     """Activation recompute with the YAML's dropout 0.1 (configs/default.yaml:13): the re-run of a layer in
     backward draws its dropout seeds again from torch's CPU generator, whose state the checkpoint restores, so
     the masks -- and with them loss and gradients -- are those of the plain run under the same torch seed."""
@@ -342,6 +343,9 @@ def test_recompute_layers_with_dropout_regenerates_the_same_masks(dev):
     for m in model.transformer.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.1
+    # (with the fp32 residual stream the two residual dropouts are torch's own, drawn from the device generator,
+    # which the checkpoint restores as well)
+    model.transformer.fp32_residual = stream32
     model.masking_strategy = _InjectedDraw(model.masking_strategy, draw)
     out = {}
     for rc in (False, True):
