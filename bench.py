@@ -368,6 +368,9 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS,
                          "traffic": tj["gemm_bytes_per_launch"] if tj else None,
+                         "traffic_source": ("profiles/r3_gemm_traffic.json: rocprofv3 --pmc passes of this command at this "
+                                            "shape on the committed tree (scripts/gpu_r3_profile.sh), not counted in this run"
+                                            if tj else None),
                          "flops_per_launch": g_fl / g_n if g_n else 0.0,
                          "avg_launch_ms": g_ms / g_n if g_n else 0.0,
                          "launches_per_step": g_n, "ms_per_step": g_ms,
