@@ -547,7 +547,10 @@ int ldm_gemm_mfma4w_bf16(int64_t M, int64_t N, int64_t K, const void *A, int64_t
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
   const int64_t items = tm * tn;
-  const int64_t nwg = items < num_cus4() ? items : num_cus4();   // persistent: one workgroup per CU
+  // persistent: one workgroup per CU (LDM_GEMM4W_WGS: fewer, for experiments on what bounds the kernel)
+  static const int wgs_env = getenv("LDM_GEMM4W_WGS") ? atoi(getenv("LDM_GEMM4W_WGS")) : 0;
+  const int64_t cus = wgs_env > 0 && wgs_env < num_cus4() ? wgs_env : num_cus4();
+  const int64_t nwg = items < cus ? items : cus;
   if (R) hipLaunchKernelGGL((gemm4w_k<true, true>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
   else if (bias) hipLaunchKernelGGL((gemm4w_k<false, true>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
   else hipLaunchKernelGGL((gemm4w_k<false, false>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, s, g);
